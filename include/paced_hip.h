@@ -1,0 +1,151 @@
+/*
+ * paced_hip.h -- C ABI of libpaced_hip.so: the gfx950 (MI355X) kernels of the PacedNegatives
+ * lceT5 training step and of the paced negative-pool selection.
+ *
+ * The reference (Parry-Parry/PacedNegatives) is pure Python and has no FFI of its own; every
+ * arithmetic step of its hot path is a call into torch / Hugging Face transformers.  Each entry
+ * point below therefore cites the reference call site (file:line under the reference checkout)
+ * or the third-party routine that call site reaches (HF:line = transformers 5.15.0
+ * models/t5/modeling_t5.py) whose device work it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed or owned by torch's allocator) unless it is
+ *     named host_*; the library never allocates, frees or synchronises;
+ *   - bf16 tensors are passed as void* (16-bit brain float, row-major, row stride in elements);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - return value: 0 on success, negative on error; paced_last_error() gives the message of the
+ *     calling thread's most recent failure;
+ *   - dropout: p in [0,1); a kept element is scaled by 1/(1-p); the decision is a pure function
+ *     of (seed, element index), so forward and backward calls that pass the same (p, seed) agree
+ *     without a stored mask.  p = 0 disables it.
+ */
+#ifndef PACED_HIP_H
+#define PACED_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int paced_abi_version(void);
+const char* paced_last_error(void);
+
+/* ---- dense contraction ------------------------------------------------------------------
+ * C = alpha * op(A) * op(B) with a fused epilogue; fp32 accumulation on the MFMA units.
+ *   trans_a = 0: A is [M][K] (lda >= K)       trans_a = 1: A is [K][M] (lda >= M)
+ *   trans_b = 0: B is [N][K] (ldb >= K)       trans_b = 1: B is [K][N] (ldb >= N)
+ * (0,0) = nn.Linear forward  y = x W^T   -- HF:304,325,326,367 (q,k,v,o), HF:84-93 (wi,wo), HF:1047 (lm_head)
+ * (0,1) = input gradient     dx = dy W    -- autograd of the above, reached from lceT5.py:155
+ * (1,1) = weight gradient    dW = dy^T x  -- idem; contraction over tokens, `splits` workgroups per
+ *                                            output tile, fp32 atomic accumulation into C
+ * epilogue:
+ *   0  C(bf16) = acc
+ *   1  C(bf16) = aux + dropout(acc)                  residual add, HF:400-401, HF:140
+ *   2  C(bf16) = dropout(relu(acc))                  HF:85-86
+ *   3  C(bf16) = aux > 0 ? acc * mask_scale : 0      backward of (2) given its saved output
+ *   4  C(f32)  = acc
+ *   5  C(f32) += acc   (atomic; required when splits > 1)
+ * Requirements: K % 64 == 0 for a non-transposed operand; N % 4 == 0; lda, ldb % 8 == 0;
+ * 16-byte aligned bases.  M, N and a transposed contraction length may be ragged. */
+int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
+                    int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                    int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
+                    float drop_p, uint32_t drop_seed, int splits, void* stream);
+
+/* ---- T5LayerNorm (RMS norm), HF:59-72; backward reached from lceT5.py:155 ------------------
+ * fwd: y = bf16(x * rsqrt(mean(x^2)+eps) * w * out_scale) then dropout; rstd[M] saved (may be NULL).
+ *      out_scale = d_model^-0.5 folds the tied-head rescale HF:1044-1045 into the final decoder norm.
+ * bwd: dx = norm_backward(dropout_mask(dy)) + dres (dres may be NULL); dw[d] += ... (fp32 atomics,
+ *      may be NULL); dx2 (may be NULL) = dropout2_mask(dx), the masked copy the preceding
+ *      sub-layer's residual branch consumes. */
+int paced_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps,
+                      float out_scale, float drop_p, uint32_t drop_seed, void* stream);
+int paced_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
+                      void* dx, void* dx2, float* dw, int M, int d, float out_scale,
+                      float drop_p, uint32_t drop_seed, float drop2_p, uint32_t drop2_seed, void* stream);
+
+/* ---- token embedding, HF:678,725 (gather + dropout) and its scatter-add gradient ------------ */
+int paced_embedding_fwd(const long long* ids, const void* table, void* out, int M, int d, int vocab,
+                        float drop_p, uint32_t drop_seed, void* stream);
+int paced_embedding_bwd(const long long* ids, const void* dout, float* dtable, int M, int d, int vocab,
+                        float drop_p, uint32_t drop_seed, void* stream);
+
+/* ---- dropout helpers (nn.Dropout, HF:86,140,400,725,745) --------------------------------- */
+int paced_dropout_apply(const void* x, void* y, size_t n, float drop_p, uint32_t drop_seed, void* stream);
+int paced_dropout_mask(float* out, size_t n, float drop_p, uint32_t drop_seed, void* stream);   /* factors, for tests */
+int paced_cast_f32_bf16(const float* x, void* y, size_t n, void* stream);
+
+/* ---- relative position bias, HF:264-279 ------------------------------------------------------
+ * tbl[h][i] = rel_bias[bucket[i]][h], i = key - query + (L-1)/2 for the encoder (L = 2S-1); the
+ * bucket of every offset (HF:217-262) is computed on the host.  bwd scatters dtbl back (atomics). */
+int paced_relbias_table_fwd(const void* rel_bias, const int* bucket, float* tbl, int H, int L, void* stream);
+int paced_relbias_table_bwd(const float* dtbl, const int* bucket, float* drel_bias, int H, int L, void* stream);
+
+/* ---- encoder self-attention, HF:144-173 with scaling = 1.0 (HF:196-197), no mask (lceT5.py:53) ----
+ * q,k,v: rows (n*S+s), head h at columns [h*64, h*64+64), row stride ld.  ctx [N*S, ldo];
+ * lse [N,H,S] fp32 (log-sum-exp of the biased scores); bias_tbl [H, 2S-1] fp32 or NULL.
+ * bwd writes dq, dk, dv (same addressing, row stride ldd) and adds into dbias_tbl (may be NULL). */
+int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, void* ctx, int ldo, float* lse,
+                       const float* bias_tbl, int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
+int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* ctx, int ldo,
+                       const void* dctx, int lddo, const float* lse, const float* bias_tbl,
+                       void* dq, void* dk_, void* dv, int ldd, float* dbias_tbl,
+                       int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
+
+/* ---- decoder attention for the 2-token target, HF:459-498 ---------------------------------------
+ * self: qkv [N*2, ld] = [q | k | v]; causal; bias2[h*2+0] = bias at offset 0, bias2[h*2+1] at -1.
+ * cross: 2 queries per sequence (qc [N*2, ldq]) over S encoder positions; kv [N*S, ldkv] holds k at
+ *        column h*64 and v at column voff + h*64; zero position bias (HF:337-342); lse [N,H,2]. */
+int paced_dec_self_attn_fwd(const void* qkv, int ld, void* ctx, int ldo, const float* bias2, int N, int H, int dk,
+                            float drop_p, uint32_t drop_seed, void* stream);
+int paced_dec_self_attn_bwd(const void* qkv, int ld, const void* dctx, int lddo, void* dqkv, int ldd,
+                            const float* bias2, float* dbias2, int N, int H, int dk,
+                            float drop_p, uint32_t drop_seed, void* stream);
+int paced_cross_attn_fwd(const void* qc, int ldq, const void* kv, int ldkv, int voff, void* ctx, int ldo, float* lse,
+                         int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
+int paced_cross_attn_bwd(const void* qc, int ldq, const void* kv, int ldkv, int voff, const void* ctx, int ldo,
+                         const void* dctx, int lddo, const float* lse, void* dqc, int lddq, void* dkv, int lddkv,
+                         int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
+
+/* ---- loss: nn.CrossEntropyLoss(ignore_index, reduction='none'), lceT5.py:110,117-118 ----------
+ * loss[r] = logsumexp(logits[r,:]) - logits[r,label[r]] (0 for ignored rows);
+ * dlogits (bf16, may be NULL) = (softmax - onehot) * gscale. */
+int paced_cross_entropy(const float* logits, const long long* labels, float* loss, void* dlogits,
+                        int rows, int V, int ldl, long long ignore_index, float gscale, void* stream);
+/* lceT5.py:119-121 after the caller's view at :134,151: ce[r] = pce[r] + sum|mean nce[r*n..(r+1)*n) */
+int paced_lce_group(const float* pce, const float* nce, float* ce, int R, int n, int use_mean, void* stream);
+/* LCEWeights.forward, lceT5.py:91-99, vectorised, plus the reductions training_step needs (:138-147):
+ * w[i] = loss[i] <= eta ? loss[i]/eta : 0;
+ * stats = { mean(w), mean(w*loss), d mean(w*loss) / d eta, mean(loss) }.  eta is read on the device. */
+int paced_lce_weights(const float* loss, const float* eta, float* w, float* stats, int R, void* stream);
+
+/* ---- transformers.AdamW as built at lceT5.py:171-172 (betas .9/.999, eps 1e-6, wd 0) ------------
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= step_size * m/(sqrt(v)+eps); p -= decay*p;
+ * g is multiplied by grad_scale first (1/world_size after a summing all-reduce).  step_size and
+ * decay are host scalars (lr * sqrt(1-b2^t)/(1-b1^t) and lr*wd).  p_bf16 (may be NULL) receives the
+ * rounded parameters the kernels read. */
+int paced_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n,
+                float beta1, float beta2, float eps, float step_size, float decay, float grad_scale, void* stream);
+
+/* ---- paced negative-pool selection ---------------------------------------------------------------
+ * Replaces the retriever call of pacednegatives/utilities/compute_all_bm25.py:26-27,36 by a dense
+ * scorer and keeps that file's contract (:37-44): per query the top-k by score.  scores = Q . Pool^T
+ * (bf16 inputs, fp32 accumulate), ordered by (score descending, pool index ascending).
+ * queries [Q, D] bf16, pool [Np, D] bf16, D % 64 == 0; out_scores f32 [Q, k], out_idx int64 [Q, k]
+ * (best first; index_base is added to every index so that pool shards can be merged).
+ * workspace: paced_pool_topk_workspace_bytes(Q, k) bytes of device memory. */
+size_t paced_pool_topk_workspace_bytes(int Q, int k);
+int paced_pool_topk(const void* queries, const void* pool, int Q, long long Np, int D, int k,
+                    long long index_base, float* out_scores, long long* out_idx,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* k-way merge of per-shard results (shards concatenated along the last axis: [Q, W*k]) into the
+ * global top-k under the same order. */
+int paced_topk_merge(const float* scores, const long long* idx, int Q, int total, int k,
+                     float* out_scores, long long* out_idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PACED_HIP_H */

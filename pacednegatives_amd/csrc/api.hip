@@ -1,0 +1,16 @@
+// Error state and version for the C-ABI library.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void paced_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* paced_last_error(void) { return g_err; }
+extern "C" int paced_abi_version(void) { return 1; }

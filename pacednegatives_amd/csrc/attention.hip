@@ -1,0 +1,700 @@
+// T5 attention kernels for gfx950 (head size 64).
+//
+//  * encoder self-attention, forward and backward: flash-style (scores never stored), scores are
+//    q.k with NO 1/sqrt(dk) scaling plus an additive bias that depends on (key - query) only, read
+//    from a per-head table staged in LDS; no padding mask (the reference drops the attention mask,
+//    pacednegatives/lceT5.py:53).  v_mfma_f32_32x32x16_bf16 throughout; every product is oriented
+//    so that the softmax row index sits on the lane and the score tile feeds the next MFMA straight
+//    from its accumulator registers (no LDS round trip for P or dS).
+//  * decoder kernels for the 2-token target ("true"/"false" + EOS): causal self-attention over 2
+//    positions and cross-attention of 2 queries over the S encoder states; these are HBM-bound
+//    vector kernels (no MFMA).
+//
+// Dropout on attention probabilities uses the counter hash of common.h with the element index
+// ((n*H + h)*Tq + q)*Tk + key, identical in forward and backward.
+#include "common.h"
+
+namespace {
+
+constexpr int DK = 64;
+
+// ---- LDS tile images: [rows][64] bf16, 128-byte rows --------------------------------------------
+// row image: 16-byte chunk c of row r stored at chunk c ^ ((r>>1)&7): conflict-free ds_read_b128
+// of one chunk column over 32 consecutive rows.
+__device__ __forceinline__ int row_img_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+// tr image: the two 64-byte halves of row r swapped when (r>>1)&1: conflict-free ds_read_b64_tr_b16
+// of 4 consecutive rows x 32 columns per half wave.
+__device__ __forceinline__ int tr_img_off(int r, int c) { return r * 128 + ((((c >> 2) ^ ((r >> 1) & 1))) << 6) + ((c & 3) << 4); }
+
+// A-operand fragment (32 rows x 16 k) read by rows: row = rb + (lane&31), k = 16*ks + 8*(lane>>5) ..+8
+__device__ __forceinline__ bf16x8 frag_rows(const char* img, int rb, int ks, int lane) {
+    const int r = rb + (lane & 31);
+    return *reinterpret_cast<const bf16x8*>(img + row_img_off(r, 2 * ks + (lane >> 5)));
+}
+// A-operand fragment of the TRANSPOSE of a [rows][64] tile: output row = column dt*32 + (lane&31) of
+// the tile, contraction index = tile row, in the permuted order an accumulator-fed B operand uses:
+// element e of lane half h <-> tile row rb + 8*(e>>2) + 4*h + (e&3).
+__device__ __forceinline__ bf16x8 frag_cols(const char* img, int rb, int dt, int lane) {
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, i = lane & 15, q4 = i >> 2, p4 = i & 3;
+    const int col = dt * 32 + 16 * g1 + 4 * p4;          // first of 4 columns this lane addresses
+    const int c = col >> 3, within = (col & 7) * 2;
+    const int r0 = rb + 4 * h + q4, r1 = r0 + 8;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + tr_img_off(r0, c) + within));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(img + tr_img_off(r1, c) + within));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// accumulator row index of register r for lane half h (32x32 C/D layout)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ bf16x8 load8(const bf16* p, bool ok) {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+    return ok ? *reinterpret_cast<const bf16x8*>(p) : z;
+}
+
+struct AttnArgs {
+    const bf16* q; const bf16* k; const bf16* v;   // row (n*S + s), head h at column h*64; row stride ld
+    int ld;
+    const bf16* o; int ldo;                        // forward output / saved context
+    const bf16* dout; int lddo;
+    bf16* out;                                     // fwd: context
+    bf16* dq; bf16* dk; bf16* dv; int ldd;         // bwd outputs, same addressing as q/k/v
+    float* lse;                                    // [N, H, S]
+    const float* bias;                             // [H, 2S-1], index key - query + S - 1 (may be null)
+    float* dbias;                                  // [H, 2S-1] fp32 atomics (may be null)
+    int N, S, H;
+    DropCfg drop;
+};
+
+// Cooperative load of a [rows<=64][64] bf16 tile (global row stride ld) into a row image and/or a tr image.
+template <int ROWS>
+__device__ __forceinline__ void stage_tile(const bf16* src, int ld, int first_row, int valid_rows, char* row_img, char* tr_img) {
+    for (int g = threadIdx.x; g < ROWS * 8; g += 256) {
+        const int r = g >> 3, c = g & 7;
+        const bf16x8 v = load8(src + (size_t)(first_row + r) * ld + c * 8, first_row + r < valid_rows);
+        if (row_img) *reinterpret_cast<bf16x8*>(row_img + row_img_off(r, c)) = v;
+        if (tr_img) *reinterpret_cast<bf16x8*>(tr_img + tr_img_off(r, c)) = v;
+    }
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(a[8 * s2 + e]);
+    return o;
+}
+
+// =================================================================================== forward
+// grid (ceil(S/128), H, N), 256 threads: wave w owns queries qb + 32w .. +32.
+__global__ void __launch_bounds__(256) enc_attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lK = smem;                 // 64 x 64 row image
+    char* lV = smem + 8192;          // 64 x 64 tr image
+    float* lbias = reinterpret_cast<float*>(smem + 16384);   // 2S + 64 floats
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5;
+    const int n = blockIdx.z, h = blockIdx.y, S = a.S;
+    const int q = blockIdx.x * 128 + w * 32 + (lane & 31);
+    const int qc = min(q, S - 1);
+    const size_t rowbase = (size_t)n * S;
+    const bf16* Q = a.q + h * DK; const bf16* K = a.k + h * DK; const bf16* V = a.v + h * DK;
+
+    for (int i = threadIdx.x; i < 2 * S + 64; i += 256)
+        lbias[i] = (a.bias && i < 2 * S - 1) ? a.bias[(size_t)h * (2 * S - 1) + i] : 0.f;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = load8(Q + (rowbase + qc) * a.ld + 16 * ks + 8 * hh, q < S);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntile = (S + 63) / 64;
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();
+        stage_tile<64>(K + rowbase * a.ld, a.ld, kt * 64, S, lK, nullptr);
+        stage_tile<64>(V + rowbase * a.ld, a.ld, kt * 64, S, nullptr, lV);
+        __syncthreads();
+
+        f32x16 s[2];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + 32 * j + acc_row(r, hh);
+                s[j][r] = lbias[key - qc + S - 1];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lK, 32 * j, ks, lane), qf[ks], s[j], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + 32 * j + acc_row(r, hh);
+                if (key >= S) s[j][r] = -INFINITY;
+                mx = fmaxf(mx, s[j][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(s[j][r] - m_new);
+                psum += p;
+                if (a.drop.thresh) {
+                    const int key = kt * 64 + 32 * j + acc_row(r, hh);
+                    s[j][r] = p * drop_factor(a.drop, (((uint64_t)n * a.H + h) * S + qc) * S + key);
+                } else {
+                    s[j][r] = p;
+                }
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(s[j], s2);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lV, 32 * j + 16 * s2, 0, lane), pf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lV, 32 * j + 16 * s2, 1, lane), pf, o1, 0, 0, 0);
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q < S) {
+        if (hh == 0 && a.lse) a.lse[((size_t)n * a.H + h) * S + q] = m_run + __logf(l_tot);
+        bf16* orow = a.out + (rowbase + q) * a.ldo + h * DK;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            bf16x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = f2bf(o0[4 * rg + e] * inv); v1[e] = f2bf(o1[4 * rg + e] * inv); }
+            *reinterpret_cast<bf16x4*>(orow + 8 * rg + 4 * hh) = v0;
+            *reinterpret_cast<bf16x4*>(orow + 32 + 8 * rg + 4 * hh) = v1;
+        }
+    }
+}
+
+// ====================================================================== backward: dK, dV, dBias
+// grid (ceil(S/128), H, N): wave w owns keys kb + 32w .. +32 and sweeps all queries in tiles of 32.
+__global__ void __launch_bounds__(256) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lQr = smem;              // 32 x 64 row image of Q
+    char* lQt = smem + 4096;       // tr image of Q
+    char* lDr = smem + 8192;       // row image of dO
+    char* lDt = smem + 12288;      // tr image of dO
+    float* llse = reinterpret_cast<float*>(smem + 16384);     // 32
+    float* ldel = llse + 32;                                  // 32
+    float* lbias = ldel + 32;                                 // 2S + 160
+    float* ldb = lbias + (2 * a.S + 160);                     // 2S + 160
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5;
+    const int n = blockIdx.z, h = blockIdx.y, S = a.S;
+    const int key = blockIdx.x * 128 + w * 32 + (lane & 31);
+    const int keyc = min(key, S - 1);
+    const size_t rowbase = (size_t)n * S;
+    const bf16* Q = a.q + h * DK; const bf16* K = a.k + h * DK; const bf16* V = a.v + h * DK;
+    const bf16* O = a.o + h * DK; const bf16* DO = a.dout + h * DK;
+    const int LB = 2 * S + 160;
+
+    for (int i = threadIdx.x; i < LB; i += 256) {
+        lbias[i] = (a.bias && i < 2 * S - 1) ? a.bias[(size_t)h * (2 * S - 1) + i] : 0.f;
+        ldb[i] = 0.f;
+    }
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = load8(K + (rowbase + keyc) * a.ld + 16 * ks + 8 * hh, key < S);
+        vf[ks] = load8(V + (rowbase + keyc) * a.ld + 16 * ks + 8 * hh, key < S);
+    }
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+
+    const int ntile = (S + 31) / 32;
+    for (int qt = 0; qt < ntile; ++qt) {
+        __syncthreads();
+        {   // stage Q and dO tiles (one 16-byte chunk per thread per matrix) and delta = rowsum(dO * O)
+            const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+            const int qrow = qt * 32 + r;
+            const bool ok = qrow < S;
+            const bf16x8 qv = load8(Q + (rowbase + qrow) * a.ld + c * 8, ok);
+            const bf16x8 dv = load8(DO + (rowbase + qrow) * a.lddo + c * 8, ok);
+            const bf16x8 ov = load8(O + (rowbase + qrow) * a.ldo + c * 8, ok);
+            *reinterpret_cast<bf16x8*>(lQr + row_img_off(r, c)) = qv;
+            *reinterpret_cast<bf16x8*>(lQt + tr_img_off(r, c)) = qv;
+            *reinterpret_cast<bf16x8*>(lDr + row_img_off(r, c)) = dv;
+            *reinterpret_cast<bf16x8*>(lDt + tr_img_off(r, c)) = dv;
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += bf2f(dv[j]) * bf2f(ov[j]);
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            if (c == 0) {
+                ldel[r] = d;
+                llse[r] = ok ? a.lse[((size_t)n * a.H + h) * S + qrow] : 0.f;
+            }
+        }
+        __syncthreads();
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = acc_row(r, hh);
+            const int qq = min(qt * 32 + ql, S - 1);
+            s[r] = lbias[keyc - qq + S - 1] - llse[ql];
+            dp[r] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lQr, 0, ks, lane), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lDr, 0, ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+        f32x16 pd;   // dropped probabilities (feeds dV); s becomes dS (feeds dK)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = acc_row(r, hh);
+            const int qq = qt * 32 + ql;
+            const bool ok = (qq < S) && (key < S);
+            const float p = ok ? __expf(s[r]) : 0.f;
+            float f = 1.f;
+            if (a.drop.thresh) f = drop_factor(a.drop, (((uint64_t)n * a.H + h) * S + min(qq, S - 1)) * S + keyc);
+            pd[r] = p * f;
+            const float ds = p * (dp[r] * f - ldel[ql]);
+            s[r] = ds;
+            if (a.dbias && ok) atomicAdd(&ldb[keyc - qq + S - 1], ds);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = pack8(pd, s2), df = pack8(s, s2);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lDt, 16 * s2, 0, lane), pf, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lDt, 16 * s2, 1, lane), pf, dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lQt, 16 * s2, 0, lane), df, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lQt, 16 * s2, 1, lane), df, dk1, 0, 0, 0);
+        }
+    }
+    if (key < S) {
+        bf16* dkrow = a.dk + (rowbase + key) * a.ldd + h * DK;
+        bf16* dvrow = a.dv + (rowbase + key) * a.ldd + h * DK;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            bf16x4 k0, k1, v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                k0[e] = f2bf(dk0[4 * rg + e]); k1[e] = f2bf(dk1[4 * rg + e]);
+                v0[e] = f2bf(dv0[4 * rg + e]); v1[e] = f2bf(dv1[4 * rg + e]);
+            }
+            *reinterpret_cast<bf16x4*>(dkrow + 8 * rg + 4 * hh) = k0;
+            *reinterpret_cast<bf16x4*>(dkrow + 32 + 8 * rg + 4 * hh) = k1;
+            *reinterpret_cast<bf16x4*>(dvrow + 8 * rg + 4 * hh) = v0;
+            *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * rg + 4 * hh) = v1;
+        }
+    }
+    if (a.dbias) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * S - 1; i += 256) {
+            const float v = ldb[i];
+            if (v != 0.f) atomicAdd(a.dbias + (size_t)h * (2 * S - 1) + i, v);
+        }
+    }
+}
+
+// ================================================================================ backward: dQ
+// grid (ceil(S/128), H, N): wave w owns queries qb + 32w .. +32 and sweeps all keys in tiles of 64.
+__global__ void __launch_bounds__(256) enc_attn_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lKr = smem;               // 64 x 64 row image of K
+    char* lKt = smem + 8192;        // tr image of K
+    char* lVr = smem + 16384;       // row image of V
+    float* lbias = reinterpret_cast<float*>(smem + 24576);    // 2S + 64
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5;
+    const int n = blockIdx.z, h = blockIdx.y, S = a.S;
+    const int q = blockIdx.x * 128 + w * 32 + (lane & 31);
+    const int qc = min(q, S - 1);
+    const size_t rowbase = (size_t)n * S;
+    const bf16* Q = a.q + h * DK; const bf16* K = a.k + h * DK; const bf16* V = a.v + h * DK;
+    const bf16* O = a.o + h * DK; const bf16* DO = a.dout + h * DK;
+
+    for (int i = threadIdx.x; i < 2 * S + 64; i += 256)
+        lbias[i] = (a.bias && i < 2 * S - 1) ? a.bias[(size_t)h * (2 * S - 1) + i] : 0.f;
+
+    bf16x8 qf[4], dof[4];
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = load8(Q + (rowbase + qc) * a.ld + 16 * ks + 8 * hh, q < S);
+        dof[ks] = load8(DO + (rowbase + qc) * a.lddo + 16 * ks + 8 * hh, q < S);
+        const bf16x8 ov = load8(O + (rowbase + qc) * a.ldo + 16 * ks + 8 * hh, q < S);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf2f(dof[ks][j]) * bf2f(ov[j]);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse = a.lse[((size_t)n * a.H + h) * S + qc];
+
+    f32x16 dq0, dq1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+
+    const int ntile = (S + 63) / 64;
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();
+        stage_tile<64>(K + rowbase * a.ld, a.ld, kt * 64, S, lKr, lKt);
+        stage_tile<64>(V + rowbase * a.ld, a.ld, kt * 64, S, lVr, nullptr);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + 32 * j + acc_row(r, hh);
+                s[r] = lbias[key - qc + S - 1] - lse;
+                dp[r] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lKr, 32 * j, ks, lane), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lVr, 32 * j, ks, lane), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + 32 * j + acc_row(r, hh);
+                const float p = (key < S) ? __expf(s[r]) : 0.f;
+                float f = 1.f;
+                if (a.drop.thresh) f = drop_factor(a.drop, (((uint64_t)n * a.H + h) * S + qc) * S + min(key, S - 1));
+                s[r] = p * (dp[r] * f - delta);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 df = pack8(s, s2);
+                dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lKt, 32 * j + 16 * s2, 0, lane), df, dq0, 0, 0, 0);
+                dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lKt, 32 * j + 16 * s2, 1, lane), df, dq1, 0, 0, 0);
+            }
+        }
+    }
+    if (q < S) {
+        bf16* dqrow = a.dq + (rowbase + q) * a.ldd + h * DK;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            bf16x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = f2bf(dq0[4 * rg + e]); v1[e] = f2bf(dq1[4 * rg + e]); }
+            *reinterpret_cast<bf16x4*>(dqrow + 8 * rg + 4 * hh) = v0;
+            *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * rg + 4 * hh) = v1;
+        }
+    }
+}
+
+// ======================================================= decoder self-attention over T = 2 positions
+// qkv rows (n*2 + t), [q | k | v] each H*64 wide.  One wave per (n, h), lane = head dimension.
+// bias2[h*2 + 0] is the bias at relative position 0, bias2[h*2 + 1] at relative position -1.
+__global__ void __launch_bounds__(256) dec_self_attn_fwd_kernel(const bf16* __restrict__ qkv, int ld, bf16* __restrict__ ctx, int ldo,
+                                                               const float* __restrict__ bias2, int N, int H, DropCfg drop) {
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= N * H) return;
+    const int n = pair / H, h = pair % H, I = H * DK;
+    const bf16* r0 = qkv + (size_t)(n * 2) * ld + h * DK + lane;
+    const bf16* r1 = r0 + ld;
+    const float q1 = bf2f(r1[0]), k0 = bf2f(r0[I]), k1 = bf2f(r1[I]), v0 = bf2f(r0[2 * I]), v1 = bf2f(r1[2 * I]);
+    const float s10 = wave_sum(q1 * k0) + bias2[h * 2 + 1];
+    const float s11 = wave_sum(q1 * k1) + bias2[h * 2 + 0];
+    const float m = fmaxf(s10, s11);
+    const float e0 = __expf(s10 - m), e1 = __expf(s11 - m);
+    const float inv = 1.f / (e0 + e1);
+    const uint64_t base = ((uint64_t)n * H + h) * 4;
+    const float p00 = 1.f * drop_factor(drop, base + 0);
+    const float p10 = e0 * inv * drop_factor(drop, base + 2);
+    const float p11 = e1 * inv * drop_factor(drop, base + 3);
+    ctx[(size_t)(n * 2) * ldo + h * DK + lane] = f2bf(p00 * v0);
+    ctx[(size_t)(n * 2 + 1) * ldo + h * DK + lane] = f2bf(p10 * v0 + p11 * v1);
+}
+
+// grid (ceil(N/32), H), 4 waves; each wave walks 8 sequences of one head and adds its bias gradient once.
+__global__ void __launch_bounds__(256) dec_self_attn_bwd_kernel(const bf16* __restrict__ qkv, int ld, const bf16* __restrict__ dctx, int lddo,
+                                                               bf16* __restrict__ dqkv, int ldd, const float* __restrict__ bias2,
+                                                               float* __restrict__ dbias2, int N, int H, DropCfg drop) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int h = blockIdx.y, I = H * DK;
+    float db0 = 0.f, db1 = 0.f;
+    for (int i = 0; i < 8; ++i) {
+        const int n = (blockIdx.x * 4 + wv) * 8 + i;
+        if (n >= N) break;
+        const bf16* r0 = qkv + (size_t)(n * 2) * ld + h * DK + lane;
+        const bf16* r1 = r0 + ld;
+        const float q1 = bf2f(r1[0]), k0 = bf2f(r0[I]), k1 = bf2f(r1[I]), v0 = bf2f(r0[2 * I]), v1 = bf2f(r1[2 * I]);
+        const float do0 = bf2f(dctx[(size_t)(n * 2) * lddo + h * DK + lane]);
+        const float do1 = bf2f(dctx[(size_t)(n * 2 + 1) * lddo + h * DK + lane]);
+        const float s10 = wave_sum(q1 * k0) + bias2[h * 2 + 1];
+        const float s11 = wave_sum(q1 * k1) + bias2[h * 2 + 0];
+        const float m = fmaxf(s10, s11);
+        const float e0 = __expf(s10 - m), e1 = __expf(s11 - m);
+        const float inv = 1.f / (e0 + e1);
+        const float p10 = e0 * inv, p11 = e1 * inv;
+        const uint64_t base = ((uint64_t)n * H + h) * 4;
+        const float f00 = drop_factor(drop, base + 0), f10 = drop_factor(drop, base + 2), f11 = drop_factor(drop, base + 3);
+        const float dp10 = wave_sum(do1 * v0) * f10, dp11 = wave_sum(do1 * v1) * f11;
+        const float delta = p10 * dp10 + p11 * dp11;
+        const float ds10 = p10 * (dp10 - delta), ds11 = p11 * (dp11 - delta);
+        bf16* d0 = dqkv + (size_t)(n * 2) * ldd + h * DK + lane;
+        bf16* d1 = d0 + ldd;
+        d0[0] = f2bf(0.f);                              // dq0: softmax over a single key has zero gradient
+        d1[0] = f2bf(ds10 * k0 + ds11 * k1);            // dq1
+        d0[I] = f2bf(ds10 * q1);                        // dk0
+        d1[I] = f2bf(ds11 * q1);                        // dk1
+        d0[2 * I] = f2bf(f00 * do0 + p10 * f10 * do1);  // dv0
+        d1[2 * I] = f2bf(p11 * f11 * do1);              // dv1
+        db1 += ds10; db0 += ds11;
+    }
+    if (dbias2 && lane == 0) {
+        atomicAdd(dbias2 + h * 2 + 0, db0);
+        atomicAdd(dbias2 + h * 2 + 1, db1);
+    }
+}
+
+// ========================================================== decoder cross-attention (2 queries x S keys)
+// q rows (n*2 + t) of qc [N*2, ldq]; keys/values rows (n*S + s) of kv [N*S, ldkv], k at column h*64,
+// v at column voff + h*64.  One wave per (n, h); 8 lanes share a key (16 bytes of the head each).
+__global__ void __launch_bounds__(256) cross_attn_fwd_kernel(const bf16* __restrict__ qc, int ldq, const bf16* __restrict__ kv, int ldkv, int voff,
+                                                            bf16* __restrict__ ctx, int ldo, float* __restrict__ lse,
+                                                            int N, int S, int H, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* sc = reinterpret_cast<float*>(smem) + (size_t)wv * 2 * S;   // scores [2][S] of this wave
+    const int pair = blockIdx.x * 4 + wv;
+    if (pair >= N * H) return;                       // whole wave leaves together; no barriers below
+    const int n = pair / H, h = pair % H;
+    const int kk = lane >> 3, c = lane & 7;
+    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qc + (size_t)(n * 2) * ldq + h * DK + c * 8);
+    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qc + (size_t)(n * 2 + 1) * ldq + h * DK + c * 8);
+    const bf16* Kb = kv + (size_t)n * S * ldkv + h * DK + c * 8;
+    const bf16* Vb = Kb + voff;
+    float m0 = -INFINITY, m1 = -INFINITY;
+    for (int k0 = 0; k0 < S; k0 += 8) {
+        const int key = k0 + kk;
+        float s0 = 0.f, s1 = 0.f;
+        if (key < S) {
+            const bf16x8 kvv = *reinterpret_cast<const bf16x8*>(Kb + (size_t)key * ldkv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0 += bf2f(q0[j]) * bf2f(kvv[j]); s1 += bf2f(q1[j]) * bf2f(kvv[j]); }
+        }
+        s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64); s0 += __shfl_xor(s0, 4, 64);
+        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+        if (key < S) {
+            if (c == 0) { sc[key] = s0; sc[S + key] = s1; }
+            m0 = fmaxf(m0, s0); m1 = fmaxf(m1, s1);
+        }
+    }
+    m0 = wave_max(m0); m1 = wave_max(m1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's score writes land before other lanes read them
+    float l0 = 0.f, l1 = 0.f;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
+    for (int k0 = 0; k0 < S; k0 += 8) {
+        const int key = k0 + kk;
+        if (key < S) {
+            const float p0 = __expf(sc[key] - m0), p1 = __expf(sc[S + key] - m1);
+            if (c == 0) { l0 += p0; l1 += p1; }
+            const uint64_t di = (((uint64_t)n * H + h) * 2) * S + key;
+            const float pd0 = p0 * drop_factor(drop, di), pd1 = p1 * drop_factor(drop, di + S);
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(Vb + (size_t)key * ldkv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a0[j] += pd0 * bf2f(vv[j]); a1[j] += pd1 * bf2f(vv[j]); }
+        }
+    }
+    l0 = wave_sum(l0); l1 = wave_sum(l1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a0[j] += __shfl_xor(a0[j], 8, 64); a0[j] += __shfl_xor(a0[j], 16, 64); a0[j] += __shfl_xor(a0[j], 32, 64);
+        a1[j] += __shfl_xor(a1[j], 8, 64); a1[j] += __shfl_xor(a1[j], 16, 64); a1[j] += __shfl_xor(a1[j], 32, 64);
+    }
+    if (kk == 0) {
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o0[j] = f2bf(a0[j] / l0); o1[j] = f2bf(a1[j] / l1); }
+        *reinterpret_cast<bf16x8*>(ctx + (size_t)(n * 2) * ldo + h * DK + c * 8) = o0;
+        *reinterpret_cast<bf16x8*>(ctx + (size_t)(n * 2 + 1) * ldo + h * DK + c * 8) = o1;
+    }
+    if (lane == 0 && lse) {
+        lse[((size_t)n * H + h) * 2 + 0] = m0 + __logf(l0);
+        lse[((size_t)n * H + h) * 2 + 1] = m1 + __logf(l1);
+    }
+}
+
+__global__ void __launch_bounds__(256) cross_attn_bwd_kernel(const bf16* __restrict__ qc, int ldq, const bf16* __restrict__ kv, int ldkv, int voff,
+                                                            const bf16* __restrict__ ctx, int ldo, const bf16* __restrict__ dctx, int lddo,
+                                                            const float* __restrict__ lse, bf16* __restrict__ dqc, int lddq,
+                                                            bf16* __restrict__ dkv, int lddkv, int N, int S, int H, DropCfg drop) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wv;
+    if (pair >= N * H) return;
+    const int n = pair / H, h = pair % H;
+    const int kk = lane >> 3, c = lane & 7;
+    const size_t qoff0 = (size_t)(n * 2) * ldq + h * DK + c * 8, qoff1 = qoff0 + ldq;
+    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qc + qoff0);
+    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qc + qoff1);
+    const bf16x8 do0 = *reinterpret_cast<const bf16x8*>(dctx + (size_t)(n * 2) * lddo + h * DK + c * 8);
+    const bf16x8 do1 = *reinterpret_cast<const bf16x8*>(dctx + (size_t)(n * 2 + 1) * lddo + h * DK + c * 8);
+    const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(ctx + (size_t)(n * 2) * ldo + h * DK + c * 8);
+    const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(ctx + (size_t)(n * 2 + 1) * ldo + h * DK + c * 8);
+    float del0 = 0.f, del1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { del0 += bf2f(do0[j]) * bf2f(o0[j]); del1 += bf2f(do1[j]) * bf2f(o1[j]); }
+    del0 += __shfl_xor(del0, 1, 64); del0 += __shfl_xor(del0, 2, 64); del0 += __shfl_xor(del0, 4, 64);
+    del1 += __shfl_xor(del1, 1, 64); del1 += __shfl_xor(del1, 2, 64); del1 += __shfl_xor(del1, 4, 64);
+    const float lse0 = lse[((size_t)n * H + h) * 2 + 0], lse1 = lse[((size_t)n * H + h) * 2 + 1];
+    const bf16* Kb = kv + (size_t)n * S * ldkv + h * DK + c * 8;
+    const bf16* Vb = Kb + voff;
+    bf16* dKb = dkv + (size_t)n * S * lddkv + h * DK + c * 8;
+    bf16* dVb = dKb + voff;
+    float dq0[8], dq1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dq0[j] = 0.f; dq1[j] = 0.f; }
+    for (int k0 = 0; k0 < S; k0 += 8) {
+        const int key = k0 + kk;
+        const bool ok = key < S;
+        bf16x8 kvv = q0, vv = q0;
+        float s0 = 0.f, s1 = 0.f, dp0 = 0.f, dp1 = 0.f;
+        if (ok) {
+            kvv = *reinterpret_cast<const bf16x8*>(Kb + (size_t)key * ldkv);
+            vv = *reinterpret_cast<const bf16x8*>(Vb + (size_t)key * ldkv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s0 += bf2f(q0[j]) * bf2f(kvv[j]); s1 += bf2f(q1[j]) * bf2f(kvv[j]);
+                dp0 += bf2f(do0[j]) * bf2f(vv[j]); dp1 += bf2f(do1[j]) * bf2f(vv[j]);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64);
+            dp0 += __shfl_xor(dp0, o, 64); dp1 += __shfl_xor(dp1, o, 64);
+        }
+        if (ok) {
+            const float p0 = __expf(s0 - lse0), p1 = __expf(s1 - lse1);
+            const uint64_t di = (((uint64_t)n * H + h) * 2) * S + key;
+            const float f0 = drop_factor(drop, di), f1 = drop_factor(drop, di + S);
+            const float ds0 = p0 * (dp0 * f0 - del0), ds1 = p1 * (dp1 * f1 - del1);
+            bf16x8 dkk, dvv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dkk[j] = f2bf(ds0 * bf2f(q0[j]) + ds1 * bf2f(q1[j]));
+                dvv[j] = f2bf(p0 * f0 * bf2f(do0[j]) + p1 * f1 * bf2f(do1[j]));
+                dq0[j] += ds0 * bf2f(kvv[j]);
+                dq1[j] += ds1 * bf2f(kvv[j]);
+            }
+            *reinterpret_cast<bf16x8*>(dKb + (size_t)key * lddkv) = dkk;
+            *reinterpret_cast<bf16x8*>(dVb + (size_t)key * lddkv) = dvv;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dq0[j] += __shfl_xor(dq0[j], 8, 64); dq0[j] += __shfl_xor(dq0[j], 16, 64); dq0[j] += __shfl_xor(dq0[j], 32, 64);
+        dq1[j] += __shfl_xor(dq1[j], 8, 64); dq1[j] += __shfl_xor(dq1[j], 16, 64); dq1[j] += __shfl_xor(dq1[j], 32, 64);
+    }
+    if (kk == 0) {
+        bf16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] = f2bf(dq0[j]); b[j] = f2bf(dq1[j]); }
+        *reinterpret_cast<bf16x8*>(dqc + (size_t)(n * 2) * lddq + h * DK + c * 8) = a;
+        *reinterpret_cast<bf16x8*>(dqc + (size_t)(n * 2 + 1) * lddq + h * DK + c * 8) = b;
+    }
+}
+
+int check_common(const char* fn, int N, int S, int H, int dk) {
+    if (dk != DK) { paced_set_error("%s: head size %d is not built (only 64)", fn, dk); return PACED_ERR_ARG; }
+    if (N <= 0 || S <= 0 || H <= 0) { paced_set_error("%s: bad shape N=%d S=%d H=%d", fn, N, S, H); return PACED_ERR_ARG; }
+    if (S > 2048) { paced_set_error("%s: sequence length %d exceeds the 2048 these kernels stage in LDS", fn, S); return PACED_ERR_ARG; }
+    return PACED_OK;
+}
+
+}  // namespace
+
+extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, void* ctx, int ldo, float* lse,
+                                  const float* bias_tbl, int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
+    if (int e = check_common("paced_enc_attn_fwd", N, S, H, dk)) return e;
+    PACED_CHECK_ARG(q && k && v && ctx, "paced_enc_attn_fwd: null operand");
+    PACED_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0, "paced_enc_attn_fwd: row strides must be multiples of 8");
+    AttnArgs a = {};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
+    a.out = (bf16*)ctx; a.ldo = ldo; a.lse = lse; a.bias = bias_tbl;
+    a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
+    const size_t smem = 16384 + (size_t)(2 * S + 64) * 4;
+    hipLaunchKernelGGL(enc_attn_fwd_kernel, dim3((S + 127) / 128, H, N), dim3(256), smem, (hipStream_t)stream, a);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* ctx, int ldo,
+                                  const void* dctx, int lddo, const float* lse, const float* bias_tbl,
+                                  void* dq, void* dk_, void* dv, int ldd, float* dbias_tbl,
+                                  int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
+    if (int e = check_common("paced_enc_attn_bwd", N, S, H, dk)) return e;
+    PACED_CHECK_ARG(q && k && v && ctx && dctx && lse && dq && dk_ && dv, "paced_enc_attn_bwd: null operand");
+    PACED_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0, "paced_enc_attn_bwd: bad row strides");
+    AttnArgs a = {};
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
+    a.o = (const bf16*)ctx; a.ldo = ldo; a.dout = (const bf16*)dctx; a.lddo = lddo;
+    a.dq = (bf16*)dq; a.dk = (bf16*)dk_; a.dv = (bf16*)dv; a.ldd = ldd;
+    a.lse = const_cast<float*>(lse); a.bias = bias_tbl; a.dbias = dbias_tbl;
+    a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
+    const dim3 grid((S + 127) / 128, H, N);
+    const size_t smem1 = 16384 + (size_t)(64 + 2 * (2 * S + 160)) * 4;
+    hipLaunchKernelGGL(enc_attn_bwd_dkdv_kernel, grid, dim3(256), smem1, (hipStream_t)stream, a);
+    PACED_CHECK_LAUNCH();
+    const size_t smem2 = 24576 + (size_t)(2 * S + 64) * 4;
+    hipLaunchKernelGGL(enc_attn_bwd_dq_kernel, grid, dim3(256), smem2, (hipStream_t)stream, a);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_dec_self_attn_fwd(const void* qkv, int ld, void* ctx, int ldo, const float* bias2, int N, int H, int dk,
+                                       float drop_p, uint32_t drop_seed, void* stream) {
+    if (int e = check_common("paced_dec_self_attn_fwd", N, 2, H, dk)) return e;
+    PACED_CHECK_ARG(qkv && ctx && bias2, "paced_dec_self_attn_fwd: null operand");
+    hipLaunchKernelGGL(dec_self_attn_fwd_kernel, dim3((N * H + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)qkv, ld, (bf16*)ctx, ldo, bias2, N, H, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_dec_self_attn_bwd(const void* qkv, int ld, const void* dctx, int lddo, void* dqkv, int ldd,
+                                       const float* bias2, float* dbias2, int N, int H, int dk,
+                                       float drop_p, uint32_t drop_seed, void* stream) {
+    if (int e = check_common("paced_dec_self_attn_bwd", N, 2, H, dk)) return e;
+    PACED_CHECK_ARG(qkv && dctx && dqkv && bias2, "paced_dec_self_attn_bwd: null operand");
+    hipLaunchKernelGGL(dec_self_attn_bwd_kernel, dim3((N + 31) / 32, H), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)qkv, ld, (const bf16*)dctx, lddo, (bf16*)dqkv, ldd, bias2, dbias2, N, H, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_cross_attn_fwd(const void* qc, int ldq, const void* kv, int ldkv, int voff, void* ctx, int ldo, float* lse,
+                                    int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
+    if (int e = check_common("paced_cross_attn_fwd", N, S, H, dk)) return e;
+    PACED_CHECK_ARG(qc && kv && ctx && lse, "paced_cross_attn_fwd: null operand");
+    PACED_CHECK_ARG(ldq % 8 == 0 && ldkv % 8 == 0 && voff % 8 == 0 && ldo % 8 == 0, "paced_cross_attn_fwd: strides must be multiples of 8");
+    hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3((N * H + 3) / 4), dim3(256), (size_t)4 * 2 * S * 4, (hipStream_t)stream,
+                       (const bf16*)qc, ldq, (const bf16*)kv, ldkv, voff, (bf16*)ctx, ldo, lse, N, S, H, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_cross_attn_bwd(const void* qc, int ldq, const void* kv, int ldkv, int voff, const void* ctx, int ldo,
+                                    const void* dctx, int lddo, const float* lse, void* dqc, int lddq, void* dkv, int lddkv,
+                                    int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
+    if (int e = check_common("paced_cross_attn_bwd", N, S, H, dk)) return e;
+    PACED_CHECK_ARG(qc && kv && ctx && dctx && lse && dqc && dkv, "paced_cross_attn_bwd: null operand");
+    PACED_CHECK_ARG(ldq % 8 == 0 && ldkv % 8 == 0 && voff % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 && lddkv % 8 == 0,
+                    "paced_cross_attn_bwd: strides must be multiples of 8");
+    hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((N * H + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)qc, ldq, (const bf16*)kv, ldkv, voff, (const bf16*)ctx, ldo, (const bf16*)dctx, lddo, lse,
+                       (bf16*)dqc, lddq, (bf16*)dkv, lddkv, N, S, H, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}

@@ -1,0 +1,53 @@
+// Internal interface of the tiled bf16 MFMA contraction kernel (gemm.hip).
+#pragma once
+#include "common.h"
+
+enum Epi : int {
+    EPI_BF16 = 0,        // C = acc
+    EPI_RES_DROP = 1,    // C = aux + dropout(acc)
+    EPI_RELU_DROP = 2,   // C = dropout(relu(acc))
+    EPI_MASK = 3,        // C = acc * (aux > 0 ? mask_scale : 0)
+    EPI_F32 = 4,         // C(f32) = acc
+    EPI_ATOMIC_F32 = 5,  // C(f32) += acc   (atomic, split-K allowed)
+    EPI_COUNT,           // ---- epilogues below are internal to the pool scorer (mining.hip)
+    EPI_TOPK_DENSE = 6,  // cand[n][m] = key(acc, row_base + m)
+    EPI_TOPK_FILTER = 7  // if acc >= thr[n]: cand[n][cnt[n]++] = key(acc, row_base + m)
+};
+
+struct GemmParams {
+    const bf16* A;
+    const bf16* B;
+    void* C;
+    const bf16* aux;
+    int M, N, K;
+    int lda, ldb, ldc, ldaux;
+    int k_per_split;   // multiple of BK
+    float alpha;       // scales acc before the epilogue
+    float mask_scale;
+    DropCfg drop;
+    // pool scorer only
+    unsigned long long* tk_cand;
+    unsigned int* tk_cnt;
+    const float* tk_thr;
+    int tk_cap;
+    unsigned int tk_row_base;
+};
+
+// Order-preserving 64-bit key: larger key <=> (higher score, then lower pool row).
+__host__ __device__ __forceinline__ unsigned long long topk_key(float score, unsigned int row) {
+    score += 0.0f;                                   // -0 -> +0
+    unsigned int u = __builtin_bit_cast(unsigned int, score);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(~row);
+}
+__host__ __device__ __forceinline__ float topk_key_score(unsigned long long key) {
+    unsigned int u = (unsigned int)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, u);
+}
+__host__ __device__ __forceinline__ unsigned int topk_key_row(unsigned long long key) { return ~(unsigned int)key; }
+
+// Launches the tiled kernel for (trans_a, trans_b, epilogue); arguments are already validated.
+int paced_gemm_launch(const GemmParams& p, bool trans_a, bool trans_b, int epilogue, int splits, hipStream_t stream);
+
+

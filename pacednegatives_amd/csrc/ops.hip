@@ -1,0 +1,467 @@
+// Memory-bound satellites of the T5 step: RMSNorm, embedding, dropout, cross-entropy, the LCE
+// loss grouping and difficulty weights, relative-position-bias tables, AdamW.  One wave per row
+// for the row-wise ops, 16-byte vector accesses throughout.
+#include "common.h"
+
+namespace {
+
+constexpr int ROW_BLOCK = 256;                 // 4 waves, one row per wave per iteration
+constexpr int MAX_ROW_GRID = 4096;
+
+__host__ int row_grid(int rows) {
+    int g = (rows + 3) / 4;
+    return g < 1 ? 1 : (g > MAX_ROW_GRID ? MAX_ROW_GRID : g);
+}
+
+// ------------------------------------------------------------------------------------------ RMSNorm
+// y = bf16(x * rsqrt(mean(x^2) + eps) * w * out_scale) [* dropout]; rstd saved in fp32.
+__global__ void __launch_bounds__(ROW_BLOCK) rmsnorm_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                               bf16* __restrict__ y, float* __restrict__ rstd,
+                                                               int M, int d, float eps, float out_scale, DropCfg drop) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nchunk = d >> 3;
+    for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+        const bf16* xr = x + (size_t)row * d;
+        float ss = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss += f * f; }
+        }
+        ss = wave_sum(ss);
+        const float rs = rsqrtf(ss / (float)d + eps);
+        if (lane == 0 && rstd) rstd[row] = rs;
+        for (int c = lane; c < nchunk; c += 64) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+            const bf16x8 wv8 = *reinterpret_cast<const bf16x8*>(w + c * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = bf2f(v[j]) * rs * bf2f(wv8[j]) * out_scale;
+                f *= drop_factor(drop, (uint64_t)row * d + c * 8 + j);
+                o[j] = f2bf(f);
+            }
+            *reinterpret_cast<bf16x8*>(y + (size_t)row * d + c * 8) = o;
+        }
+    }
+}
+
+// Backward of the above, fused with the residual-stream add and (optionally) the dropout mask of
+// the sub-layer that precedes this norm in the forward pass:
+//   dyo = dy * dropmask(drop)                          (dropout on the norm output, final norms only)
+//   g   = dyo * w * out_scale ;  xh = x * rstd
+//   dx  = rstd * (g - xh * mean(g * xh)) + dres
+//   dw += sum_rows dyo * xh * out_scale                 (fp32 atomics, one per column per workgroup)
+//   dx2 = dx * dropmask(drop2)                          (optional second output)
+constexpr int NORM_MAX_CHUNKS = 4;                       // d <= 2048
+__global__ void __launch_bounds__(ROW_BLOCK) rmsnorm_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                               const bf16* __restrict__ w, const float* __restrict__ rstd,
+                                                               const bf16* __restrict__ dres, bf16* __restrict__ dx,
+                                                               bf16* __restrict__ dx2, float* __restrict__ dw,
+                                                               int M, int d, float out_scale, DropCfg drop, DropCfg drop2) {
+    __shared__ float red[4][2048];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nchunk = d >> 3;
+    float dwacc[NORM_MAX_CHUNKS][8];
+#pragma unroll
+    for (int i = 0; i < NORM_MAX_CHUNKS; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwacc[i][j] = 0.f;
+
+    for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+        const float rs = rstd[row];
+        float g[NORM_MAX_CHUNKS][8], xh[NORM_MAX_CHUNKS][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * d + c * 8);
+                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (size_t)row * d + c * 8);
+                const bf16x8 wv8 = *reinterpret_cast<const bf16x8*>(w + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float dyo = bf2f(dv[j]) * drop_factor(drop, (uint64_t)row * d + c * 8 + j);
+                    xh[i][j] = bf2f(xv[j]) * rs;
+                    g[i][j] = dyo * bf2f(wv8[j]) * out_scale;
+                    dwacc[i][j] += dyo * xh[i][j] * out_scale;
+                    dot += g[i][j] * xh[i][j];
+                }
+            }
+        }
+        dot = wave_sum(dot) / (float)d;
+#pragma unroll
+        for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
+                bf16x8 r8;
+                if (dres) r8 = *reinterpret_cast<const bf16x8*>(dres + (size_t)row * d + c * 8);
+                bf16x8 o, o2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = rs * (g[i][j] - xh[i][j] * dot);
+                    if (dres) v += bf2f(r8[j]);
+                    o[j] = f2bf(v);
+                    o2[j] = f2bf(bf2f(o[j]) * drop_factor(drop2, (uint64_t)row * d + c * 8 + j));
+                }
+                *reinterpret_cast<bf16x8*>(dx + (size_t)row * d + c * 8) = o;
+                if (dx2) *reinterpret_cast<bf16x8*>(dx2 + (size_t)row * d + c * 8) = o2;
+            }
+        }
+    }
+    if (!dw) return;
+#pragma unroll
+    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wv][c * 8 + j] = dwacc[i][j];
+        }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < d; col += ROW_BLOCK) {
+        const float s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+        atomicAdd(dw + col, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- embedding
+__global__ void __launch_bounds__(ROW_BLOCK) embedding_fwd_kernel(const long long* __restrict__ ids, const bf16* __restrict__ table,
+                                                                 bf16* __restrict__ out, int M, int d, int vocab, DropCfg drop) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nchunk = d >> 3;
+    for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+        long long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);     // ids are validated on the host; clamp keeps the load in range
+        for (int c = lane; c < nchunk; c += 64) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(table + (size_t)id * d + c * 8);
+            if (drop.thresh) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * drop_factor(drop, (uint64_t)row * d + c * 8 + j));
+            }
+            *reinterpret_cast<bf16x8*>(out + (size_t)row * d + c * 8) = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(ROW_BLOCK) embedding_bwd_kernel(const long long* __restrict__ ids, const bf16* __restrict__ dout,
+                                                                 float* __restrict__ dtable, int M, int d, int vocab, DropCfg drop) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+        long long id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        // one dword per lane, 256 contiguous bytes per wave instruction: the shape float atomics run fastest in
+        for (int col = lane; col < d; col += 64) {
+            const float v = bf2f(dout[(size_t)row * d + col]) * drop_factor(drop, (uint64_t)row * d + col);
+            atomicAdd(dtable + (size_t)id * d + col, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dropout
+__global__ void __launch_bounds__(256) dropout_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8, DropCfg drop) {
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n8; c += (size_t)gridDim.x * 256) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(x + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * drop_factor(drop, c * 8 + j));
+        *reinterpret_cast<bf16x8*>(y + c * 8) = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) dropout_mask_kernel(float* __restrict__ out, size_t n, DropCfg drop) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = drop_factor(drop, i);
+}
+
+// -------------------------------------------------------------------------------------------- casts
+__global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t n) {
+    const size_t n4 = n >> 2;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += (size_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + c * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+        *reinterpret_cast<bf16x4*>(y + c * 4) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[n4 * 4 + threadIdx.x] = f2bf(x[n4 * 4 + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------ cross-entropy
+// One workgroup per logits row (fp32, V columns).  loss = logsumexp(row) - row[label]; rows whose
+// label equals ignore_index give loss 0 and a zero gradient.  dlogits (optional, bf16) =
+// (softmax - onehot) * gscale.
+__device__ __forceinline__ void block_reduce_max_sum(float& m, float& s, float* sh) {
+    // combine (max, sum-exp) pairs: wave level then across the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, m2);
+        s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+        m = mn;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[wv * 2] = m; sh[wv * 2 + 1] = s; }
+    __syncthreads();
+    float M = sh[0], S = sh[1];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const float m2 = sh[i * 2], s2 = sh[i * 2 + 1];
+        const float mn = fmaxf(M, m2);
+        S = S * __expf(M - mn) + s2 * __expf(m2 - mn);
+        M = mn;
+    }
+    m = M; s = S;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                float* __restrict__ loss, bf16* __restrict__ dlogits,
+                                                int V, int ldl, long long ignore_index, float gscale) {
+    __shared__ float sh[8];
+    const int row = blockIdx.x;
+    const float* lr = logits + (size_t)row * ldl;
+    const long long label = labels[row];
+    float m = -INFINITY, s = 0.f;
+    const int n4 = V >> 2;
+    for (int c = threadIdx.x; c < n4; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lr + c * 4);
+        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        const float mn = fmaxf(m, mx);
+        s = s * __expf(m - mn) + __expf(v[0] - mn) + __expf(v[1] - mn) + __expf(v[2] - mn) + __expf(v[3] - mn);
+        m = mn;
+    }
+    block_reduce_max_sum(m, s, sh);
+    const float lse = m + __logf(s);
+    const bool ignored = (label == ignore_index) || label < 0 || label >= V;
+    if (threadIdx.x == 0) loss[row] = ignored ? 0.f : lse - lr[label];
+    if (!dlogits) return;
+    bf16* dr = dlogits + (size_t)row * ldl;
+    const float g = ignored ? 0.f : gscale;
+    for (int c = threadIdx.x; c < n4; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lr + c * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float p = __expf(v[j] - lse);
+            if ((long long)(c * 4 + j) == label) p -= 1.f;
+            o[j] = f2bf(p * g);
+        }
+        *reinterpret_cast<bf16x4*>(dr + c * 4) = o;
+    }
+}
+
+// ----------------------------------------------------------------------- LCE grouping and weights
+// ce[r] = pce[r] + (sum | mean) nce[r*n .. (r+1)*n)        r in [0, R)
+__global__ void lce_group_kernel(const float* __restrict__ pce, const float* __restrict__ nce, float* __restrict__ ce,
+                                 int R, int n, int use_mean) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int j = 0; j < n; ++j) s += nce[(size_t)r * n + j];
+    if (use_mean) s /= (float)n;
+    ce[r] = pce[r] + s;
+}
+
+// w_i = loss_i/eta if loss_i <= eta else 0 ; stats = {mean w, mean w*loss, d mean(w*loss)/d eta, mean loss}
+__global__ void __launch_bounds__(256) lce_weights_kernel(const float* __restrict__ loss, const float* __restrict__ eta_p,
+                                                         float* __restrict__ w, float* __restrict__ stats, int R) {
+    __shared__ float sh[4][4];
+    const float eta = eta_p[0];
+    float sw = 0.f, swl = 0.f, sg = 0.f, sl = 0.f;
+    for (int i = threadIdx.x; i < R; i += 256) {
+        const float l = loss[i];
+        const bool hard = l > eta;
+        const float wi = hard ? 0.f : l / eta;
+        w[i] = wi;
+        sw += wi; swl += wi * l; sl += l;
+        if (!hard) sg -= l * l / (eta * eta);
+    }
+    sw = wave_sum(sw); swl = wave_sum(swl); sg = wave_sum(sg); sl = wave_sum(sl);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[wv][0] = sw; sh[wv][1] = swl; sh[wv][2] = sg; sh[wv][3] = sl; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        stats[threadIdx.x] = t / (float)R;
+    }
+}
+
+// ------------------------------------------------------------------- relative-position-bias tables
+// tbl[h][i] = rel_bias[bucket[i]][h] for i in [0, L): the additive bias as a function of
+// (key - query) only; the bucket of each offset is computed on the host.
+__global__ void relbias_table_fwd_kernel(const bf16* __restrict__ rel_bias, const int* __restrict__ bucket,
+                                         float* __restrict__ tbl, int H, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * L) return;
+    const int h = i / L, j = i % L;
+    tbl[i] = bf2f(rel_bias[bucket[j] * H + h]);
+}
+__global__ void relbias_table_bwd_kernel(const float* __restrict__ dtbl, const int* __restrict__ bucket,
+                                         float* __restrict__ drel_bias, int H, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * L) return;
+    const int h = i / L, j = i % L;
+    atomicAdd(drel_bias + bucket[j] * H + h, dtbl[i]);
+}
+
+// -------------------------------------------------------------------------------------------- AdamW
+// Hugging Face AdamW (the optimiser the reference constructs): m = b1 m + (1-b1) g;
+// v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v) + eps); then p -= lr*wd*p.  step_size
+// (= lr * sqrt(1-b2^t)/(1-b1^t)) is computed on the host.  Also refreshes the bf16 shadow copy.
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16* __restrict__ pb, size_t n,
+                                                   float b1, float b2, float eps, float step_size, float decay, float gscale) {
+    const size_t n4 = n >> 2;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += (size_t)gridDim.x * 256) {
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + c * 4);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c * 4);
+        f32x4 mv = *reinterpret_cast<f32x4*>(m + c * 4);
+        f32x4 vv = *reinterpret_cast<f32x4*>(v + c * 4);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = gv[j] * gscale;
+            mv[j] = mv[j] * b1 + gj * (1.f - b1);
+            vv[j] = vv[j] * b2 + gj * gj * (1.f - b2);
+            pv[j] = pv[j] - step_size * (mv[j] / (sqrtf(vv[j]) + eps));
+            pv[j] = pv[j] - decay * pv[j];
+            o[j] = f2bf(pv[j]);
+        }
+        *reinterpret_cast<f32x4*>(p + c * 4) = pv;
+        *reinterpret_cast<f32x4*>(m + c * 4) = mv;
+        *reinterpret_cast<f32x4*>(v + c * 4) = vv;
+        if (pb) *reinterpret_cast<bf16x4*>(pb + c * 4) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        const float gj = g[i] * gscale;
+        const float mj = m[i] * b1 + gj * (1.f - b1);
+        const float vj = v[i] * b2 + gj * gj * (1.f - b2);
+        float pj = p[i] - step_size * (mj / (sqrtf(vj) + eps));
+        pj -= decay * pj;
+        p[i] = pj; m[i] = mj; v[i] = vj;
+        if (pb) pb[i] = f2bf(pj);
+    }
+}
+
+int flat_grid(size_t work_items) {
+    size_t g = (work_items + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int paced_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps,
+                                 float out_scale, float drop_p, uint32_t drop_seed, void* stream) {
+    PACED_CHECK_ARG(x && w && y, "paced_rmsnorm_fwd: null operand");
+    PACED_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0, "paced_rmsnorm_fwd: need M > 0 and d a positive multiple of 8 (got %d, %d)", M, d);
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(row_grid(M)), dim3(ROW_BLOCK), 0, (hipStream_t)stream,
+                       (const bf16*)x, (const bf16*)w, (bf16*)y, rstd, M, d, eps, out_scale, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
+                                 void* dx, void* dx2, float* dw, int M, int d, float out_scale,
+                                 float drop_p, uint32_t drop_seed, float drop2_p, uint32_t drop2_seed, void* stream) {
+    PACED_CHECK_ARG(dy && x && w && rstd && dx, "paced_rmsnorm_bwd: null operand");
+    PACED_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && d <= 2048, "paced_rmsnorm_bwd: need M > 0 and d a multiple of 8 up to 2048 (got %d, %d)", M, d);
+    int grid = row_grid(M);
+    if (grid > 1024) grid = 1024;   // bounds the per-column atomics on dw
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid), dim3(ROW_BLOCK), 0, (hipStream_t)stream,
+                       (const bf16*)dy, (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx2, dw,
+                       M, d, out_scale, make_drop(drop_p, drop_seed), make_drop(drop2_p, drop2_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_embedding_fwd(const long long* ids, const void* table, void* out, int M, int d, int vocab,
+                                   float drop_p, uint32_t drop_seed, void* stream) {
+    PACED_CHECK_ARG(ids && table && out, "paced_embedding_fwd: null operand");
+    PACED_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && vocab > 0, "paced_embedding_fwd: bad shape M=%d d=%d vocab=%d", M, d, vocab);
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(row_grid(M)), dim3(ROW_BLOCK), 0, (hipStream_t)stream,
+                       ids, (const bf16*)table, (bf16*)out, M, d, vocab, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_embedding_bwd(const long long* ids, const void* dout, float* dtable, int M, int d, int vocab,
+                                   float drop_p, uint32_t drop_seed, void* stream) {
+    PACED_CHECK_ARG(ids && dout && dtable, "paced_embedding_bwd: null operand");
+    PACED_CHECK_ARG(M > 0 && d > 0 && vocab > 0, "paced_embedding_bwd: bad shape M=%d d=%d vocab=%d", M, d, vocab);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(row_grid(M)), dim3(ROW_BLOCK), 0, (hipStream_t)stream,
+                       ids, (const bf16*)dout, dtable, M, d, vocab, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_dropout_apply(const void* x, void* y, size_t n, float drop_p, uint32_t drop_seed, void* stream) {
+    PACED_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "paced_dropout_apply: need n a positive multiple of 8");
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(flat_grid(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (bf16*)y, n / 8, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_dropout_mask(float* out, size_t n, float drop_p, uint32_t drop_seed, void* stream) {
+    PACED_CHECK_ARG(out && n > 0, "paced_dropout_mask: bad arguments");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(flat_grid(n)), dim3(256), 0, (hipStream_t)stream, out, n, make_drop(drop_p, drop_seed));
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_cast_f32_bf16(const float* x, void* y, size_t n, void* stream) {
+    PACED_CHECK_ARG(x && y && n > 0, "paced_cast_f32_bf16: bad arguments");
+    PACED_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, "paced_cast_f32_bf16: misaligned");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(flat_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, n);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_cross_entropy(const float* logits, const long long* labels, float* loss, void* dlogits,
+                                   int rows, int V, int ldl, long long ignore_index, float gscale, void* stream) {
+    PACED_CHECK_ARG(logits && labels && loss, "paced_cross_entropy: null operand");
+    PACED_CHECK_ARG(rows > 0 && V > 0 && V % 4 == 0 && ldl % 4 == 0 && ldl >= V, "paced_cross_entropy: need V, ldl multiples of 4 (rows=%d V=%d ldl=%d)", rows, V, ldl);
+    hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, labels, loss, (bf16*)dlogits, V, ldl, ignore_index, gscale);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_lce_group(const float* pce, const float* nce, float* ce, int R, int n, int use_mean, void* stream) {
+    PACED_CHECK_ARG(pce && nce && ce && R > 0 && n > 0, "paced_lce_group: bad arguments");
+    hipLaunchKernelGGL(lce_group_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, pce, nce, ce, R, n, use_mean);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_lce_weights(const float* loss, const float* eta, float* w, float* stats, int R, void* stream) {
+    PACED_CHECK_ARG(loss && eta && w && stats && R > 0, "paced_lce_weights: bad arguments");
+    hipLaunchKernelGGL(lce_weights_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss, eta, w, stats, R);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_relbias_table_fwd(const void* rel_bias, const int* bucket, float* tbl, int H, int L, void* stream) {
+    PACED_CHECK_ARG(rel_bias && bucket && tbl && H > 0 && L > 0, "paced_relbias_table_fwd: bad arguments");
+    hipLaunchKernelGGL(relbias_table_fwd_kernel, dim3((H * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)rel_bias, bucket, tbl, H, L);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_relbias_table_bwd(const float* dtbl, const int* bucket, float* drel_bias, int H, int L, void* stream) {
+    PACED_CHECK_ARG(dtbl && bucket && drel_bias && H > 0 && L > 0, "paced_relbias_table_bwd: bad arguments");
+    hipLaunchKernelGGL(relbias_table_bwd_kernel, dim3((H * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, dtbl, bucket, drel_bias, H, L);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+extern "C" int paced_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n,
+                           float beta1, float beta2, float eps, float step_size, float decay, float grad_scale, void* stream) {
+    PACED_CHECK_ARG(p && g && m && v && n > 0, "paced_adamw: bad arguments");
+    PACED_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)p_bf16 & 7) == 0, "paced_adamw: misaligned buffers");
+    hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
+                       p, g, m, v, (bf16*)p_bf16, n, beta1, beta2, eps, step_size, decay, grad_scale);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}

@@ -1,0 +1,287 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point).
+
+torch supplies device memory and the current HIP stream; every computation happens in
+libpaced_hip.so.  Shapes are validated here so that a kernel is never launched on operands that do
+not match what its grid assumes.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+EPI_BF16, EPI_RES_DROP, EPI_RELU_DROP, EPI_MASK, EPI_F32, EPI_ATOMIC_F32 = range(6)
+BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _rows2d(t, name):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name} must be 2-D with unit inner stride, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0)
+
+
+def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, alpha=1.0, mask_scale=1.0,
+         drop_p=0.0, drop_seed=0, splits=1):
+    """c = alpha * op(a) op(b) with a fused epilogue (see include/paced_hip.h)."""
+    lib = _lib.load()
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(aux, BF16, "aux")
+    _chk(c, F32 if epilogue in (EPI_F32, EPI_ATOMIC_F32) else BF16, "c")
+    lda, ldb, ldc = _rows2d(a, "a"), _rows2d(b, "b"), _rows2d(c, "c")
+    M, N = c.shape
+    K = a.shape[0] if trans_a else a.shape[1]
+    if (a.shape[1] if trans_a else a.shape[0]) != M:
+        raise ValueError(f"a {tuple(a.shape)} does not give M={M} (trans_a={trans_a})")
+    if (b.shape[1] if trans_b else b.shape[0]) != N or (b.shape[0] if trans_b else b.shape[1]) != K:
+        raise ValueError(f"b {tuple(b.shape)} does not give N={N}, K={K} (trans_b={trans_b})")
+    ldaux = 0
+    if aux is not None:
+        if tuple(aux.shape) != (M, N):
+            raise ValueError("aux must have the shape of c")
+        ldaux = _rows2d(aux, "aux")
+    _lib.check(lib.paced_gemm_bf16(_p(a), _p(b), _p(c), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
+                                   int(trans_a), int(trans_b), epilogue, alpha, mask_scale, drop_p, drop_seed, splits,
+                                   _stream()), "paced_gemm_bf16")
+    return c
+
+
+def rmsnorm_fwd(x, w, y, rstd=None, *, eps=1e-6, out_scale=1.0, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    _chk(x, BF16, "x"); _chk(w, BF16, "w"); _chk(y, BF16, "y"); _chk(rstd, F32, "rstd")
+    M, d = x.shape
+    assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape and w.numel() == d
+    assert rstd is None or rstd.numel() >= M
+    _lib.check(lib.paced_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), M, d, eps, out_scale, drop_p, drop_seed, _stream()), "paced_rmsnorm_fwd")
+    return y
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dx, *, dres=None, dx2=None, dw=None, out_scale=1.0, drop_p=0.0, drop_seed=0,
+                drop2_p=0.0, drop2_seed=0):
+    lib = _lib.load()
+    for t, n in ((dy, "dy"), (x, "x"), (w, "w"), (dres, "dres"), (dx, "dx"), (dx2, "dx2")):
+        _chk(t, BF16, n)
+    _chk(rstd, F32, "rstd"); _chk(dw, F32, "dw")
+    M, d = x.shape
+    for t in (dy, x, dx, dres, dx2):
+        assert t is None or (t.is_contiguous() and tuple(t.shape) == (M, d))
+    assert dw is None or dw.numel() == d
+    _lib.check(lib.paced_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dx2), _p(dw), M, d, out_scale,
+                                     drop_p, drop_seed, drop2_p, drop2_seed, _stream()), "paced_rmsnorm_bwd")
+    return dx
+
+
+def embedding_fwd(ids, table, out, *, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    _chk(ids, I64, "ids"); _chk(table, BF16, "table"); _chk(out, BF16, "out")
+    M = ids.numel()
+    V, d = table.shape
+    assert ids.is_contiguous() and table.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (M, d)
+    _lib.check(lib.paced_embedding_fwd(_p(ids), _p(table), _p(out), M, d, V, drop_p, drop_seed, _stream()), "paced_embedding_fwd")
+    return out
+
+
+def embedding_bwd(ids, dout, dtable, *, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    _chk(ids, I64, "ids"); _chk(dout, BF16, "dout"); _chk(dtable, F32, "dtable")
+    M = ids.numel()
+    V, d = dtable.shape
+    assert ids.is_contiguous() and dout.is_contiguous() and dtable.is_contiguous() and tuple(dout.shape) == (M, d)
+    _lib.check(lib.paced_embedding_bwd(_p(ids), _p(dout), _p(dtable), M, d, V, drop_p, drop_seed, _stream()), "paced_embedding_bwd")
+
+
+def dropout_apply(x, y, *, drop_p, drop_seed):
+    lib = _lib.load()
+    _chk(x, BF16, "x"); _chk(y, BF16, "y")
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    _lib.check(lib.paced_dropout_apply(_p(x), _p(y), x.numel(), drop_p, drop_seed, _stream()), "paced_dropout_apply")
+    return y
+
+
+def dropout_mask(n, *, drop_p, drop_seed, device="cuda"):
+    lib = _lib.load()
+    out = torch.empty(n, dtype=F32, device=device)
+    _lib.check(lib.paced_dropout_mask(_p(out), n, drop_p, drop_seed, _stream()), "paced_dropout_mask")
+    return out
+
+
+def cast_f32_bf16(x, y):
+    lib = _lib.load()
+    _chk(x, F32, "x"); _chk(y, BF16, "y")
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    _lib.check(lib.paced_cast_f32_bf16(_p(x), _p(y), x.numel(), _stream()), "paced_cast_f32_bf16")
+    return y
+
+
+def relbias_table_fwd(rel_bias, bucket, tbl):
+    lib = _lib.load()
+    _chk(rel_bias, BF16, "rel_bias"); _chk(bucket, I32, "bucket"); _chk(tbl, F32, "tbl")
+    H, L = tbl.shape
+    assert rel_bias.is_contiguous() and rel_bias.shape[1] == H and bucket.numel() == L and tbl.is_contiguous()
+    _lib.check(lib.paced_relbias_table_fwd(_p(rel_bias), _p(bucket), _p(tbl), H, L, _stream()), "paced_relbias_table_fwd")
+    return tbl
+
+
+def relbias_table_bwd(dtbl, bucket, drel_bias):
+    lib = _lib.load()
+    _chk(dtbl, F32, "dtbl"); _chk(bucket, I32, "bucket"); _chk(drel_bias, F32, "drel_bias")
+    H, L = dtbl.shape
+    assert drel_bias.is_contiguous() and drel_bias.shape[1] == H and bucket.numel() == L and dtbl.is_contiguous()
+    _lib.check(lib.paced_relbias_table_bwd(_p(dtbl), _p(bucket), _p(drel_bias), H, L, _stream()), "paced_relbias_table_bwd")
+
+
+def enc_attn_fwd(q, k, v, ctx, lse, bias_tbl, N, S, H, *, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx")):
+        _chk(t, BF16, n)
+    _chk(lse, F32, "lse"); _chk(bias_tbl, F32, "bias_tbl")
+    ld = _rows2d(q, "q")
+    assert _rows2d(k, "k") == ld and _rows2d(v, "v") == ld
+    assert q.shape[0] == N * S and q.shape[1] == H * 64 and k.shape == q.shape and v.shape == q.shape
+    assert ctx.shape == q.shape and lse.numel() == N * H * S and lse.is_contiguous()
+    assert bias_tbl is None or (tuple(bias_tbl.shape) == (H, 2 * S - 1) and bias_tbl.is_contiguous())
+    _lib.check(lib.paced_enc_attn_fwd(_p(q), _p(k), _p(v), ld, _p(ctx), _rows2d(ctx, "ctx"), _p(lse), _p(bias_tbl),
+                                      N, S, H, 64, drop_p, drop_seed, _stream()), "paced_enc_attn_fwd")
+    return ctx
+
+
+def enc_attn_bwd(q, k, v, ctx, dctx, lse, bias_tbl, dq, dk, dv, dbias_tbl, N, S, H, *, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx"), (dctx, "dctx"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk(t, BF16, n)
+    _chk(lse, F32, "lse"); _chk(bias_tbl, F32, "bias_tbl"); _chk(dbias_tbl, F32, "dbias_tbl")
+    ld, ldd = _rows2d(q, "q"), _rows2d(dq, "dq")
+    assert _rows2d(k, "k") == ld and _rows2d(v, "v") == ld and _rows2d(dk, "dk") == ldd and _rows2d(dv, "dv") == ldd
+    for t in (q, k, v, ctx, dctx, dq, dk, dv):
+        assert tuple(t.shape) == (N * S, H * 64)
+    assert lse.numel() == N * H * S and lse.is_contiguous()
+    for t in (bias_tbl, dbias_tbl):
+        assert t is None or (tuple(t.shape) == (H, 2 * S - 1) and t.is_contiguous())
+    _lib.check(lib.paced_enc_attn_bwd(_p(q), _p(k), _p(v), ld, _p(ctx), _rows2d(ctx, "ctx"), _p(dctx), _rows2d(dctx, "dctx"),
+                                      _p(lse), _p(bias_tbl), _p(dq), _p(dk), _p(dv), ldd, _p(dbias_tbl),
+                                      N, S, H, 64, drop_p, drop_seed, _stream()), "paced_enc_attn_bwd")
+
+
+def dec_self_attn_fwd(qkv, ctx, bias2, N, H, *, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    _chk(qkv, BF16, "qkv"); _chk(ctx, BF16, "ctx"); _chk(bias2, F32, "bias2")
+    assert tuple(qkv.shape) == (N * 2, 3 * H * 64) and tuple(ctx.shape) == (N * 2, H * 64) and bias2.numel() == 2 * H
+    _lib.check(lib.paced_dec_self_attn_fwd(_p(qkv), _rows2d(qkv, "qkv"), _p(ctx), _rows2d(ctx, "ctx"), _p(bias2), N, H, 64,
+                                           drop_p, drop_seed, _stream()), "paced_dec_self_attn_fwd")
+    return ctx
+
+
+def dec_self_attn_bwd(qkv, dctx, dqkv, bias2, dbias2, N, H, *, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    _chk(qkv, BF16, "qkv"); _chk(dctx, BF16, "dctx"); _chk(dqkv, BF16, "dqkv"); _chk(bias2, F32, "bias2"); _chk(dbias2, F32, "dbias2")
+    assert tuple(qkv.shape) == (N * 2, 3 * H * 64) and tuple(dqkv.shape) == tuple(qkv.shape) and tuple(dctx.shape) == (N * 2, H * 64)
+    assert bias2.numel() == 2 * H and (dbias2 is None or dbias2.numel() == 2 * H)
+    _lib.check(lib.paced_dec_self_attn_bwd(_p(qkv), _rows2d(qkv, "qkv"), _p(dctx), _rows2d(dctx, "dctx"), _p(dqkv), _rows2d(dqkv, "dqkv"),
+                                           _p(bias2), _p(dbias2), N, H, 64, drop_p, drop_seed, _stream()), "paced_dec_self_attn_bwd")
+
+
+def cross_attn_fwd(qc, kv, ctx, lse, N, S, H, *, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    _chk(qc, BF16, "qc"); _chk(kv, BF16, "kv"); _chk(ctx, BF16, "ctx"); _chk(lse, F32, "lse")
+    I = H * 64
+    assert tuple(qc.shape) == (N * 2, I) and tuple(kv.shape) == (N * S, 2 * I) and tuple(ctx.shape) == (N * 2, I)
+    assert lse.numel() == N * H * 2 and lse.is_contiguous()
+    _lib.check(lib.paced_cross_attn_fwd(_p(qc), _rows2d(qc, "qc"), _p(kv), _rows2d(kv, "kv"), I, _p(ctx), _rows2d(ctx, "ctx"), _p(lse),
+                                        N, S, H, 64, drop_p, drop_seed, _stream()), "paced_cross_attn_fwd")
+    return ctx
+
+
+def cross_attn_bwd(qc, kv, ctx, dctx, lse, dqc, dkv, N, S, H, *, drop_p=0.0, drop_seed=0):
+    lib = _lib.load()
+    for t, n in ((qc, "qc"), (kv, "kv"), (ctx, "ctx"), (dctx, "dctx"), (dqc, "dqc"), (dkv, "dkv")):
+        _chk(t, BF16, n)
+    _chk(lse, F32, "lse")
+    I = H * 64
+    assert tuple(qc.shape) == (N * 2, I) and tuple(kv.shape) == (N * S, 2 * I) and tuple(ctx.shape) == (N * 2, I)
+    assert tuple(dctx.shape) == (N * 2, I) and tuple(dqc.shape) == (N * 2, I) and tuple(dkv.shape) == (N * S, 2 * I)
+    _lib.check(lib.paced_cross_attn_bwd(_p(qc), _rows2d(qc, "qc"), _p(kv), _rows2d(kv, "kv"), I, _p(ctx), _rows2d(ctx, "ctx"),
+                                        _p(dctx), _rows2d(dctx, "dctx"), _p(lse), _p(dqc), _rows2d(dqc, "dqc"), _p(dkv), _rows2d(dkv, "dkv"),
+                                        N, S, H, 64, drop_p, drop_seed, _stream()), "paced_cross_attn_bwd")
+
+
+def cross_entropy(logits, labels, loss, dlogits=None, *, ignore_index=-100, gscale=1.0):
+    lib = _lib.load()
+    _chk(logits, F32, "logits"); _chk(labels, I64, "labels"); _chk(loss, F32, "loss"); _chk(dlogits, BF16, "dlogits")
+    R, V = logits.shape
+    ldl = _rows2d(logits, "logits")
+    assert labels.numel() == R and labels.is_contiguous() and loss.numel() == R
+    assert dlogits is None or (tuple(dlogits.shape) == (R, V) and _rows2d(dlogits, "dlogits") == ldl)
+    _lib.check(lib.paced_cross_entropy(_p(logits), _p(labels), _p(loss), _p(dlogits), R, V, ldl, ignore_index, gscale, _stream()), "paced_cross_entropy")
+    return loss
+
+
+def lce_group(pce, nce, ce, n, use_mean):
+    lib = _lib.load()
+    _chk(pce, F32, "pce"); _chk(nce, F32, "nce"); _chk(ce, F32, "ce")
+    R = pce.numel()
+    assert nce.numel() == R * n and ce.numel() == R
+    _lib.check(lib.paced_lce_group(_p(pce), _p(nce), _p(ce), R, n, int(bool(use_mean)), _stream()), "paced_lce_group")
+    return ce
+
+
+def lce_weights(loss, eta, w, stats):
+    lib = _lib.load()
+    _chk(loss, F32, "loss"); _chk(eta, F32, "eta"); _chk(w, F32, "w"); _chk(stats, F32, "stats")
+    R = loss.numel()
+    assert w.numel() == R and stats.numel() >= 4 and eta.numel() == 1
+    _lib.check(lib.paced_lce_weights(_p(loss), _p(eta), _p(w), _p(stats), R, _stream()), "paced_lce_weights")
+    return w
+
+
+def adamw(p, g, m, v, p_bf16, *, beta1=0.9, beta2=0.999, eps=1e-6, step_size, decay=0.0, grad_scale=1.0):
+    lib = _lib.load()
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, F32, n)
+        assert t.is_contiguous() and t.numel() == p.numel()
+    _chk(p_bf16, BF16, "p_bf16")
+    assert p_bf16 is None or (p_bf16.is_contiguous() and p_bf16.numel() == p.numel())
+    _lib.check(lib.paced_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), beta1, beta2, eps, step_size, decay, grad_scale,
+                               _stream()), "paced_adamw")
+
+
+def pool_topk(queries, pool, k, *, index_base=0, workspace=None):
+    """Exact top-k of queries @ pool.T per query: (scores f32 [Q,k], idx i64 [Q,k]), best first."""
+    lib = _lib.load()
+    _chk(queries, BF16, "queries"); _chk(pool, BF16, "pool")
+    Q, D = queries.shape
+    Np = pool.shape[0]
+    assert pool.shape[1] == D and queries.is_contiguous() and pool.is_contiguous()
+    need = lib.paced_pool_topk_workspace_bytes(Q, k)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=queries.device)
+    scores = torch.empty(Q, k, dtype=F32, device=queries.device)
+    idx = torch.empty(Q, k, dtype=I64, device=queries.device)
+    _lib.check(lib.paced_pool_topk(_p(queries), _p(pool), Q, Np, D, k, index_base, _p(scores), _p(idx), _p(workspace), workspace.numel(),
+                                   _stream()), "paced_pool_topk")
+    return scores, idx
+
+
+def topk_merge(scores, idx, k):
+    lib = _lib.load()
+    _chk(scores, F32, "scores"); _chk(idx, I64, "idx")
+    Q, total = scores.shape
+    assert idx.shape == scores.shape and scores.is_contiguous() and idx.is_contiguous()
+    out_s = torch.empty(Q, k, dtype=F32, device=scores.device)
+    out_i = torch.empty(Q, k, dtype=I64, device=scores.device)
+    _lib.check(lib.paced_topk_merge(_p(scores), _p(idx), Q, total, k, _p(out_s), _p(out_i), _stream()), "paced_topk_merge")
+    return out_s, out_i

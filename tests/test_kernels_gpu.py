@@ -1,0 +1,424 @@
+"""Per-kernel parity tests through the C ABI (ctypes) against plain fp32 torch math on the same inputs.
+
+Integer-valued inputs are used wherever an exact answer exists (every product and partial sum is
+exactly representable, so the result is independent of summation order): those checks are bit-exact.
+Floating-point checks state their tolerance next to the comparison.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pacednegatives_amd import kernels as K  # noqa: E402
+
+DEV = "cuda"
+
+
+def ints(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).float()
+
+
+def bf(x):
+    return x.to(DEV).to(torch.bfloat16).contiguous()
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (300, 136, 128), (1, 8, 64), (257, 520, 192), (1000, 768, 256)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_exact_integers(M, N, K_, ta, tb):
+    if ta and M % 8:
+        M = (M + 7) // 8 * 8
+    Kc = K_ if not ta else K_ + 24          # ragged token contraction is allowed for transposed operands
+    if not ta and tb:
+        Kc = K_
+    a = ints((M, Kc), -3, 3, 1)
+    b = ints((N, Kc), -3, 3, 2)
+    want = (a @ b.t())                       # |sum| <= 9*280: exact in fp32
+    A = bf(a.t() if ta else a)
+    B = bf(b.t() if tb else b)
+    c = torch.full((M, N), float("nan"), device=DEV)
+    K.gemm(A, B, c, trans_a=ta, trans_b=tb, epilogue=K.EPI_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(c.cpu(), want)
+
+
+def test_gemm_strided_views_and_alpha():
+    a = ints((200, 128), -2, 2, 3)
+    b = ints((72, 128), -2, 2, 4)
+    Abig = bf(torch.cat([a, a + 1], dim=1))           # lda = 256, use the first 128 columns
+    B = bf(b)
+    cbig = torch.zeros(200, 80, device=DEV)
+    K.gemm(Abig[:, :128], B, cbig[:, :72], epilogue=K.EPI_F32, alpha=0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(cbig[:, :72].cpu(), 0.5 * (a @ b.t()))
+    assert (cbig[:, 72:] == 0).all()
+
+
+def test_gemm_epilogues():
+    M, N, Kc = 260, 256, 128
+    a, b = ints((M, Kc), -2, 2, 5), ints((N, Kc), -2, 2, 6)
+    res = ints((M, N), -20, 20, 7)
+    A, B, R = bf(a), bf(b), bf(res)
+    acc = a @ b.t()
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    K.gemm(A, B, out, epilogue=K.EPI_BF16)
+    assert torch.equal(out.float().cpu(), acc.to(torch.bfloat16).float())
+    K.gemm(A, B, out, epilogue=K.EPI_RES_DROP, aux=R)
+    assert torch.equal(out.float().cpu(), (acc + res).to(torch.bfloat16).float())
+    inplace = R.clone()
+    K.gemm(A, B, inplace, epilogue=K.EPI_RES_DROP, aux=inplace)
+    assert torch.equal(inplace.float().cpu(), (acc + res).to(torch.bfloat16).float())
+    K.gemm(A, B, out, epilogue=K.EPI_RELU_DROP)
+    assert torch.equal(out.float().cpu(), acc.clamp_min(0).to(torch.bfloat16).float())
+    K.gemm(A, B, out, epilogue=K.EPI_MASK, aux=R, mask_scale=2.0)
+    assert torch.equal(out.float().cpu(), torch.where(res > 0, acc * 2.0, torch.zeros_like(acc)).to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("splits", [1, 3, 8])
+def test_gemm_weight_gradient_atomic_split(splits):
+    Mtok, No, Ko = 1000, 136, 192                     # dW[No,Ko] = dY[Mtok,No]^T X[Mtok,Ko]
+    dy, x = ints((Mtok, No), -2, 2, 8), ints((Mtok, Ko), -2, 2, 9)
+    c = torch.ones(No, Ko, device=DEV)
+    K.gemm(bf(dy), bf(x), c, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=splits)
+    torch.cuda.synchronize()
+    assert torch.equal(c.cpu(), 1.0 + dy.t() @ x)
+
+
+def test_gemm_float_tolerance():
+    M, N, Kc = 512, 768, 3072
+    a, b = rnd((M, Kc), 10), rnd((N, Kc), 11, Kc ** -0.5)
+    A, B = bf(a), bf(b)
+    c = torch.empty(M, N, device=DEV)
+    K.gemm(A, B, c, epilogue=K.EPI_F32)
+    want = A.float() @ B.float().t()
+    # same bf16 inputs, fp32 accumulation in a different order: 1e-5 relative to the row scale
+    assert (c - want).abs().max().item() < 1e-4 * want.abs().max().item()
+
+
+def test_gemm_dropout_matches_mask_function():
+    M, N, Kc = 192, 128, 64
+    a, b = ints((M, Kc), -2, 2, 12), ints((N, Kc), -2, 2, 13)
+    acc = (a @ b.t()).to(DEV)
+    p, seed = 0.25, 1234
+    mask = K.dropout_mask(M * N, drop_p=p, drop_seed=seed).view(M, N)
+    keep = (mask > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.02
+    assert torch.allclose(mask[mask > 0], torch.tensor(1 / (1 - p), device=DEV))
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    K.gemm(bf(a), bf(b), out, epilogue=K.EPI_RELU_DROP, drop_p=p, drop_seed=seed)
+    assert torch.equal(out.float(), (acc.clamp_min(0) * mask).to(torch.bfloat16).float())
+    res = bf(ints((M, N), -9, 9, 14))
+    K.gemm(bf(a), bf(b), out, epilogue=K.EPI_RES_DROP, aux=res, drop_p=p, drop_seed=seed)
+    assert torch.equal(out.float(), (res.float() + acc * mask).to(torch.bfloat16).float())
+    y = torch.empty(M * N, device=DEV, dtype=torch.bfloat16)
+    x = bf(acc.cpu().reshape(-1))
+    K.dropout_apply(x, y, drop_p=p, drop_seed=seed)
+    assert torch.equal(y.float(), (x.float() * mask.view(-1)).to(torch.bfloat16).float())
+
+
+def test_gemm_rejects_bad_shapes():
+    from pacednegatives_amd._lib import PacedHipError
+    A, B = bf(torch.zeros(64, 72)), bf(torch.zeros(64, 72))
+    with pytest.raises(PacedHipError, match="multiple of 64"):
+        K.gemm(A, B, torch.zeros(64, 64, device=DEV), epilogue=K.EPI_F32)
+
+
+# --------------------------------------------------------------------------------- norm / embedding
+@pytest.mark.parametrize("M,d", [(5, 128), (333, 768), (64, 1024)])
+def test_rmsnorm_fwd_bwd(M, d):
+    x = bf(rnd((M, d), 20, 3.0))
+    w = bf(1.0 + 0.1 * rnd((d,), 21))
+    dy = bf(rnd((M, d), 22))
+    dres = bf(rnd((M, d), 23))
+    y = torch.empty_like(x)
+    rstd = torch.empty(M, device=DEV)
+    K.rmsnorm_fwd(x, w, y, rstd, out_scale=0.5)
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    yr = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * wf * 0.5
+    assert torch.equal(y.float(), yr.detach().to(torch.bfloat16).float()) or (y.float() - yr.detach()).abs().max() < 2e-2
+    # bf16 output: at most 1 ulp (2^-8 relative) from the fp32 value
+    assert ((y.float() - yr.detach()).abs() <= yr.detach().abs() * 2 ** -7 + 1e-6).all()
+    np.testing.assert_allclose(rstd.cpu().numpy(), torch.rsqrt(x.float().pow(2).mean(-1) + 1e-6).cpu().numpy(), rtol=1e-5)
+    yr.backward(dy.float())
+    dx = torch.empty_like(x)
+    dw = torch.zeros(d, device=DEV)
+    K.rmsnorm_bwd(dy, x, w, rstd, dx, dres=dres, dw=dw, out_scale=0.5)
+    want_dx = xf.grad + dres.float()
+    assert ((dx.float() - want_dx).abs() <= want_dx.abs() * 2 ** -7 + 1e-3 * want_dx.abs().max()).all()
+    np.testing.assert_allclose(dw.cpu().numpy(), wf.grad.cpu().numpy(), rtol=2e-3, atol=2e-3 * wf.grad.abs().max().item())
+
+
+def test_rmsnorm_bwd_second_output_is_masked_copy():
+    M, d = 40, 256
+    x, w, dy = bf(rnd((M, d), 24)), bf(torch.ones(d)), bf(rnd((M, d), 25))
+    rstd = torch.empty(M, device=DEV)
+    y = torch.empty_like(x)
+    K.rmsnorm_fwd(x, w, y, rstd)
+    dx, dx2 = torch.empty_like(x), torch.empty_like(x)
+    K.rmsnorm_bwd(dy, x, w, rstd, dx, dx2=dx2, drop2_p=0.1, drop2_seed=77)
+    mask = K.dropout_mask(M * d, drop_p=0.1, drop_seed=77).view(M, d)
+    assert torch.equal(dx2.float(), (dx.float() * mask).to(torch.bfloat16).float())
+
+
+def test_embedding_fwd_bwd():
+    V, d, M = 1000, 128, 777
+    table = bf(rnd((V, d), 30))
+    g = torch.Generator().manual_seed(31)
+    ids = torch.randint(0, V, (M,), generator=g).to(DEV)
+    out = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    K.embedding_fwd(ids, table, out)
+    assert torch.equal(out, table[ids])
+    dout = bf(ints((M, d), -3, 3, 32))
+    dtable = torch.zeros(V, d, device=DEV)
+    K.embedding_bwd(ids, dout, dtable)
+    want = torch.zeros(V, d, device=DEV).index_add_(0, ids, dout.float())
+    assert torch.equal(dtable, want)
+
+
+# -------------------------------------------------------------------------------------- attention
+def _bias_table(H, S, seed):
+    return (rnd((H, 2 * S - 1), seed, 0.5)).to(DEV).contiguous()
+
+
+def _dense_bias(tbl, S):
+    idx = torch.arange(S, device=DEV)[None, :] - torch.arange(S, device=DEV)[:, None] + S - 1   # [q, k]
+    return tbl[:, idx]                                                                       # [H, q, k]
+
+
+def _ref_attention(q, k, v, bias, N, S, H, mask=None):
+    qh = q.float().view(N, S, H, 64).transpose(1, 2)
+    kh = k.float().view(N, S, H, 64).transpose(1, 2)
+    vh = v.float().view(N, S, H, 64).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3) + bias[None]
+    p = torch.softmax(s, dim=-1)
+    lse = torch.logsumexp(s, dim=-1)
+    if mask is not None:
+        p = p * mask
+    o = (p @ vh).transpose(1, 2).reshape(N * S, H * 64)
+    return o, lse
+
+
+@pytest.mark.parametrize("N,S,H", [(2, 16, 2), (1, 100, 3), (3, 128, 2), (2, 256, 12), (1, 333, 1)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_enc_attention_fwd_bwd(N, S, H, p):
+    I = H * 64
+    qkv = bf(rnd((N * S, 3 * I), 40, 0.35))
+    q, k, v = qkv[:, :I], qkv[:, I:2 * I], qkv[:, 2 * I:]
+    tbl = _bias_table(H, S, 41)
+    ctx = torch.empty(N * S, I, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(N * H * S, device=DEV)
+    seed = 99
+    K.enc_attn_fwd(q, k, v, ctx, lse, tbl, N, S, H, drop_p=p, drop_seed=seed)
+    mask = None
+    if p > 0:
+        mask = K.dropout_mask(N * H * S * S, drop_p=p, drop_seed=seed).view(N, H, S, S)
+    ql, kl, vl = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+    tl = tbl.clone().requires_grad_(True)
+    o_ref, lse_ref = _ref_attention(ql, kl, vl, _dense_bias(tl, S), N, S, H, mask)
+    scale = o_ref.abs().max().item()
+    # probabilities and the output are rounded to bf16 inside the kernel: 2^-8 relative steps
+    assert (ctx.float() - o_ref).abs().max().item() < 1.5e-2 * scale
+    np.testing.assert_allclose(lse.view(N, H, S).cpu().numpy(), lse_ref.detach().cpu().numpy(), rtol=1e-4, atol=2e-4)
+
+    dctx = bf(rnd((N * S, I), 42))
+    o_ref.backward(dctx.float())
+    dqkv = torch.full((N * S, 3 * I), float("nan"), device=DEV, dtype=torch.bfloat16)
+    dtbl = torch.zeros_like(tbl)
+    K.enc_attn_bwd(q, k, v, ctx, dctx, lse, tbl, dqkv[:, :I], dqkv[:, I:2 * I], dqkv[:, 2 * I:], dtbl, N, S, H,
+                   drop_p=p, drop_seed=seed)
+    for got, want, name in ((dqkv[:, :I], ql.grad, "dq"), (dqkv[:, I:2 * I], kl.grad, "dk"), (dqkv[:, 2 * I:], vl.grad, "dv")):
+        err = (got.float() - want).abs().max().item()
+        assert err < 2.5e-2 * want.abs().max().item(), (name, err, want.abs().max().item())
+    err = (dtbl - tl.grad).abs().max().item()
+    assert err < 2e-2 * tl.grad.abs().max().item() + 1e-3, ("dbias", err)
+
+
+def test_enc_attention_rescale_branch_forced():
+    """One key far above the rest in a late tile forces the online-softmax running-max update."""
+    N, S, H, I = 1, 192, 1, 64
+    q = rnd((S, I), 50, 0.2)
+    k = rnd((S, I), 51, 0.2)
+    v = rnd((S, I), 52)
+    k[150] = q[7] * 40.0                      # query 7 . key 150 is huge; other rows see it as ordinary noise * 40
+    qkv = bf(torch.cat([q, k, v], dim=1))
+    ctx = torch.empty(S, I, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(S, device=DEV)
+    tbl = torch.zeros(1, 2 * S - 1, device=DEV)
+    K.enc_attn_fwd(qkv[:, :I], qkv[:, I:2 * I], qkv[:, 2 * I:], ctx, lse, tbl, N, S, H)
+    o_ref, lse_ref = _ref_attention(qkv[:, :I], qkv[:, I:2 * I], qkv[:, 2 * I:], _dense_bias(tbl, S), N, S, H)
+    assert (ctx.float() - o_ref).abs().max().item() < 2e-2 * o_ref.abs().max().item()
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref.view(-1).cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_decoder_self_attention(p):
+    N, H = 37, 3
+    I = H * 64
+    qkv = bf(rnd((N * 2, 3 * I), 60, 0.3))
+    bias2 = rnd((H, 2), 61, 0.5).to(DEV).contiguous()       # [:,0] offset 0, [:,1] offset -1
+    ctx = torch.empty(N * 2, I, device=DEV, dtype=torch.bfloat16)
+    K.dec_self_attn_fwd(qkv, ctx, bias2, N, H, drop_p=p, drop_seed=5)
+    mask = K.dropout_mask(N * H * 4, drop_p=p, drop_seed=5).view(N, H, 2, 2) if p > 0 else torch.ones(N, H, 2, 2, device=DEV)
+    x = qkv.float().detach().clone().requires_grad_(True)
+    b2 = bias2.clone().requires_grad_(True)
+    qh, kh, vh = (x[:, i * I:(i + 1) * I].view(N, 2, H, 64).transpose(1, 2) for i in range(3))
+    bias = torch.stack([torch.stack([b2[:, 0], b2[:, 0]], -1), torch.stack([b2[:, 1], b2[:, 0]], -1)], -2)   # [H, q, k]
+    s = qh @ kh.transpose(2, 3) + bias[None]
+    s = s.masked_fill(torch.tensor([[False, True], [False, False]], device=DEV), float("-inf"))
+    o = ((torch.softmax(s, -1) * mask) @ vh).transpose(1, 2).reshape(N * 2, I)
+    assert (ctx.float() - o).abs().max().item() < 1e-2 * o.abs().max().item()
+    dctx = bf(rnd((N * 2, I), 62))
+    o.backward(dctx.float())
+    dqkv = torch.empty_like(qkv)
+    db2 = torch.zeros(H, 2, device=DEV)
+    K.dec_self_attn_bwd(qkv, dctx, dqkv, bias2, db2, N, H, drop_p=p, drop_seed=5)
+    assert (dqkv.float() - x.grad).abs().max().item() < 1.5e-2 * x.grad.abs().max().item()
+    np.testing.assert_allclose(db2.cpu().numpy(), b2.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,S,H", [(3, 16, 2), (2, 101, 3), (5, 256, 12)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_cross_attention(N, S, H, p):
+    I = H * 64
+    qc = bf(rnd((N * 2, I), 70, 0.3))
+    kv = bf(rnd((N * S, 2 * I), 71, 0.4))
+    ctx = torch.empty(N * 2, I, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(N * H * 2, device=DEV)
+    K.cross_attn_fwd(qc, kv, ctx, lse, N, S, H, drop_p=p, drop_seed=8)
+    mask = K.dropout_mask(N * H * 2 * S, drop_p=p, drop_seed=8).view(N, H, 2, S) if p > 0 else 1.0
+    ql = qc.float().detach().clone().requires_grad_(True)
+    kvl = kv.float().detach().clone().requires_grad_(True)
+    qh = ql.view(N, 2, H, 64).transpose(1, 2)
+    kh = kvl[:, :I].view(N, S, H, 64).transpose(1, 2)
+    vh = kvl[:, I:].view(N, S, H, 64).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3)
+    o = ((torch.softmax(s, -1) * mask) @ vh).transpose(1, 2).reshape(N * 2, I)
+    assert (ctx.float() - o).abs().max().item() < 1e-2 * o.abs().max().item()
+    np.testing.assert_allclose(lse.view(N, H, 2).cpu().numpy(), torch.logsumexp(s, -1).detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    dctx = bf(rnd((N * 2, I), 72))
+    o.backward(dctx.float())
+    dqc = torch.empty_like(qc)
+    dkv = torch.full_like(kv, float("nan"))
+    K.cross_attn_bwd(qc, kv, ctx, dctx, lse, dqc, dkv, N, S, H, drop_p=p, drop_seed=8)
+    assert (dqc.float() - ql.grad).abs().max().item() < 1.5e-2 * ql.grad.abs().max().item()
+    assert (dkv.float() - kvl.grad).abs().max().item() < 1.5e-2 * kvl.grad.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------ loss / optimiser
+def test_cross_entropy_and_lce():
+    R, V = 24, 32128
+    logits = (rnd((R, V), 80, 2.0)).to(DEV).contiguous()
+    labels = torch.tensor([1176, 1] * (R // 2)).to(DEV)
+    labels[5] = -100
+    loss = torch.empty(R, device=DEV)
+    dl = torch.empty(R, V, device=DEV, dtype=torch.bfloat16)
+    K.cross_entropy(logits, labels, loss, dl, gscale=0.25)
+    ll = logits.clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(ll, labels, ignore_index=-100, reduction="none")
+    np.testing.assert_allclose(loss.cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    (want.sum() * 0.25).backward()
+    assert (dl.float() - ll.grad).abs().max().item() < 2 ** -8 * ll.grad.abs().max().item() + 1e-7
+    assert (dl[5] == 0).all()
+    # grouping: rows r of pce with n consecutive entries of nce
+    B, n = 6, 3
+    pce, nce = rnd((B * 2,), 81).abs().to(DEV), rnd((B * n * 2,), 82).abs().to(DEV)
+    ce = torch.empty(B * 2, device=DEV)
+    K.lce_group(pce, nce, ce, n, False)
+    assert torch.allclose(ce, pce + nce.view(-1, n).sum(1))
+    K.lce_group(pce, nce, ce, n, True)
+    assert torch.allclose(ce, pce + nce.view(-1, n).mean(1))
+
+
+def test_lce_weights_known_answer():
+    loss = torch.tensor([0.1, 0.5, 2.0, 0.3], device=DEV)
+    eta = torch.tensor([0.4], device=DEV)
+    w = torch.empty(4, device=DEV)
+    stats = torch.empty(4, device=DEV)
+    K.lce_weights(loss, eta, w, stats)
+    np.testing.assert_allclose(w.cpu().numpy(), [0.25, 0.0, 0.0, 0.75], rtol=1e-6)
+    np.testing.assert_allclose(stats.cpu().numpy(), [0.25, (0.025 + 0.225) / 4, -0.15625, 0.725], rtol=1e-5)
+
+
+def test_adamw_matches_hf_rule():
+    n = 1003
+    p0, g = rnd((n,), 90), rnd((n,), 91, 1e-3)
+    p = p0.to(DEV).clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    pr, mr, vr = p0.double().clone(), torch.zeros(n).double(), torch.zeros(n).double()
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-6
+    for t in range(1, 4):
+        step = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        K.adamw(p, g.to(DEV), m, v, pb, step_size=step)
+        mr = b1 * mr + (1 - b1) * g.double()
+        vr = b2 * vr + (1 - b2) * g.double() ** 2
+        pr = pr - step * mr / (vr.sqrt() + eps)
+    np.testing.assert_allclose(p.cpu().numpy(), pr.float().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(pb, p.to(torch.bfloat16))
+
+
+def test_relbias_tables():
+    H, S = 4, 50
+    rel = bf(rnd((32, H), 95))
+    g = torch.Generator().manual_seed(96)
+    bucket = torch.randint(0, 32, (2 * S - 1,), generator=g).int().to(DEV)
+    tbl = torch.empty(H, 2 * S - 1, device=DEV)
+    K.relbias_table_fwd(rel, bucket, tbl)
+    assert torch.equal(tbl, rel.float()[bucket.long()].t().contiguous())
+    dt = ints((H, 2 * S - 1), -2, 2, 97).to(DEV)
+    drel = torch.zeros(32, H, device=DEV)
+    K.relbias_table_bwd(dt, bucket, drel)
+    want = torch.zeros(32, H, device=DEV).index_add_(0, bucket.long(), dt.t().contiguous())
+    assert torch.equal(drel, want)
+
+
+# ------------------------------------------------------------------------------------------ mining
+def test_pool_topk_golden(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "mining.npz"))
+    k = int(g["k"][0])
+    s, i = K.pool_topk(bf(torch.from_numpy(g["q"])), bf(torch.from_numpy(g["p"])), k)
+    assert np.array_equal(i.cpu().numpy(), g["idx"])
+    assert np.array_equal(s.cpu().numpy(), g["scores"])
+
+
+@pytest.mark.parametrize("Q,Np,D,k", [(40, 50000, 128, 100), (130, 20001, 64, 1000), (7, 300, 64, 1000)])
+def test_pool_topk_exact_vs_oracle(Q, Np, D, k):
+    from oracle import mining_ref
+    rng = np.random.RandomState(3)
+    q = rng.randint(-8, 9, size=(Q, D)).astype(np.float32)
+    p = rng.randint(-8, 9, size=(Np, D)).astype(np.float32)
+    p[Np // 2:] = np.abs(p[Np // 2:])           # later rows score differently: thresholds keep moving
+    s, i = K.pool_topk(bf(torch.from_numpy(q)), bf(torch.from_numpy(p)), k, index_base=0)
+    ws, wi = mining_ref.pool_topk(q, p, min(k, Np))
+    kk = min(k, Np)
+    assert np.array_equal(i.cpu().numpy()[:, :kk], wi)
+    assert np.array_equal(s.cpu().numpy()[:, :kk], ws)
+    if kk < k:
+        assert (i.cpu().numpy()[:, kk:] == -1).all()
+
+
+def test_topk_merge_of_shards():
+    from oracle import mining_ref
+    rng = np.random.RandomState(4)
+    Q, Np, D, k, W = 9, 4000, 64, 64, 4
+    q = rng.randint(-8, 9, size=(Q, D)).astype(np.float32)
+    p = rng.randint(-8, 9, size=(Np, D)).astype(np.float32)
+    parts_s, parts_i = [], []
+    for r in range(W):
+        lo, hi = r * Np // W, (r + 1) * Np // W
+        s, i = K.pool_topk(bf(torch.from_numpy(q)), bf(torch.from_numpy(p[lo:hi])), k, index_base=lo)
+        parts_s.append(s); parts_i.append(i)
+    ms, mi = K.topk_merge(torch.cat(parts_s, 1).contiguous(), torch.cat(parts_i, 1).contiguous(), k)
+    ws, wi = mining_ref.pool_topk(q, p, k)
+    assert np.array_equal(mi.cpu().numpy(), wi) and np.array_equal(ms.cpu().numpy(), ws)
