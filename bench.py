@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the lceT5 training step (and, as a secondary figure, the negative-pool scorer).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one reference-faithful ``LCEModel.training_step`` (two no-grad T5 forwards, the LCE loss,
+the eta meta-update, two forwards with state, backward, AdamW; dropout 0.1 active as under Lightning's
+train mode) over one synthetic batch that is already resident in HBM.  Workload at every N: the
+per-GPU shard of the configuration the metric is quoted on -- T5-base, K=16 negatives, seq_len 256,
+global batch 256 over 8 GPUs = 32 tuples per GPU (weak scaling: per-GPU work is fixed).  With N > 1
+the driver starts one process per GPU (torch.distributed.run); gradients are all-reduced over RCCL.
+
+Rank 0 prints ONE JSON line.  ``roofline`` refers to the dominant kernel (the bf16 MFMA contraction
+``gemm_bf16_kernel``): algorithmic FLOPs of its launches divided by their summed duration, measured
+with HIP events on the launch stream during one extra instrumented step run right after the timed
+region (instrumenting the timed steps themselves would add event overhead to ``value``).
+``cpu_baseline`` times the CPU oracle (fp32 torch restatement of the reference step) on the box's
+host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BF16_DENSE_PEAK = 2.5e15     # FLOP/s, MI355X dense bf16 MFMA
+HBM_PEAK = 8.0e12            # B/s
+
+
+def t5_forward_flops(dims, S, T=2):
+    """Algorithmic FLOPs of one sequence's forward (2 per MAC; GEMMs, attention products, LM head)."""
+    d, I, ff, V = dims.d_model, dims.inner, dims.d_ff, dims.vocab_size
+    enc = dims.num_layers * (8 * S * d * I + 4 * S * S * I + 4 * S * d * ff)
+    dec = dims.num_decoder_layers * (8 * T * d * I + 4 * T * T * I + 2 * T * d * I + 4 * S * d * I + 4 * T * S * I
+                                     + 2 * T * I * d + 4 * T * d * ff)
+    return enc + dec + 2 * T * d * V
+
+
+def run_train(args, rank, world, device):
+    from pacednegatives_amd import kernels as K
+    from pacednegatives_amd.config import resolve
+    from pacednegatives_amd.lceT5 import LCEModel
+    from pacednegatives_amd.synthetic import token_batch
+    import torch.distributed as dist
+
+    dims = resolve(args.model)
+    B, nneg, S = args.batch, args.n_neg, args.seq
+    hp = {"model_name": args.model, "total_steps": 100000 // B, "eta": 0.3466, "batch_size": B, "lr": 1e-3, "meta_lr": 1e-3,
+          "n": nneg, "warmup_steps": 10000 // B, "use_mean": False, "ignore_index": -100, "dropout": args.dropout, "seed": 0}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = LCEModel(hp, device=device)
+    batch = token_batch(B, nneg, S, dims.vocab_size, seed=1234 + rank, device=device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.training_step(batch, i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.training_step(batch, args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # one instrumented step: per-launch HIP events around the contraction kernel
+    roof = None
+    K.PROFILE = []
+    model.training_step(batch, args.warmup + args.steps)
+    torch.cuda.synchronize()
+    prof, K.PROFILE = K.PROFILE, None
+    by_sym = {}
+    for key, flops, e0, e1 in prof:
+        ms = e0.elapsed_time(e1)
+        s = by_sym.setdefault(key, [0.0, 0.0, 0])
+        s[0] += flops; s[1] += ms * 1e-3; s[2] += 1
+    tot_f = sum(v[0] for v in by_sym.values())
+    tot_t = sum(v[1] for v in by_sym.values())
+    if tot_t > 0:
+        dom = max(by_sym.items(), key=lambda kv: kv[1][1])
+        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": tot_f / tot_t / 1e12, "peak": BF16_DENSE_PEAK / 1e12,
+                "unit": "TFLOP/s", "frac": tot_f / tot_t / BF16_DENSE_PEAK, "traffic": None,
+                "launches": sum(v[2] for v in by_sym.values()), "avg_launch_us": tot_t / sum(v[2] for v in by_sym.values()) * 1e6,
+                "slowest_variant": {"trans_a,trans_b,epilogue": dom[0], "TFLOP/s": dom[1][0] / dom[1][1] / 1e12,
+                                    "launches": dom[1][2], "avg_launch_us": dom[1][1] / dom[1][2] * 1e6},
+                "gemm_share_of_step": tot_t / (elapsed / args.steps)}
+    F = t5_forward_flops(dims, S)
+    tuples_per_s = world * B * args.steps / elapsed
+    flops_per_tuple = 4 * (1 + nneg) * F
+    out = {
+        "metric": "training tuples/sec (q + 1+K docs) at T5-base, K=16", "value": tuples_per_s, "unit": "tuples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"lceT5 training_step, {args.model} random-init, K={nneg} negatives, seq_len={S}, "
+                               f"{B} tuples per GPU (global batch {B * world}), dropout {args.dropout}, "
+                               "reference-faithful 4 forwards + backward + 2 AdamW",
+                   "parallelism": f"dp{world}", "global_batch": B * world, "seq_len": S},
+        "roofline": roof,
+        "step_mfma_frac": tuples_per_s * flops_per_tuple / (world * BF16_DENSE_PEAK),
+        "algorithmic_flops_per_tuple": flops_per_tuple,
+    }
+    return out, model
+
+
+def cpu_baseline(args, dims):
+    """Oracle (fp32 CPU restatement of the reference step) on a bounded sample: 1 tuple of the same shape."""
+    from oracle import lce_ref
+    from oracle.t5_ref import T5Dims as RefDims, init_params
+    from pacednegatives_amd.synthetic import token_batch
+    rd = RefDims(dims.vocab_size, dims.d_model, dims.d_kv, dims.num_heads, dims.d_ff, dims.num_layers, dims.num_decoder_layers)
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    B = 1
+    P = init_params(rd, 0)
+    eta = torch.tensor([0.3466])
+    opt, meta = lce_ref.HFAdamW(P, 1e-3), lce_ref.HFAdamW({"eta": eta}, 1e-3)
+    p, n = token_batch(B, args.n_neg, args.seq, dims.vocab_size, seed=1234)
+    steps = 0
+    t_used = 0.0
+    for i in range(1 + args.cpu_steps):
+        t0 = time.perf_counter()
+        lce_ref.training_step(P, rd, eta, opt, meta, i, p["input_ids"], p["labels"], n["input_ids"], n["labels"], args.n_neg,
+                              False, 10000, 100000)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            t_used += dt; steps += 1
+        if t_used > 25.0:
+            break
+    return {"value": B * steps / t_used, "unit": "tuples/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} timed steps (after 1 warm-up) of B=1 tuple (1+{args.n_neg} sequences x {args.seq} tokens), "
+                      f"{args.model} dims, fp32, dropout 0, torch CPU"}
+
+
+def run_mining(args, rank, world, device):
+    """Secondary figure: pool rows are sharded over ranks, queries replicated, shard results merged."""
+    from pacednegatives_amd import kernels as K
+    import torch.distributed as dist
+    Q, D, k = args.mine_queries, 768, args.mine_k
+    Np = args.mine_pool // world
+    g = torch.Generator(device=device).manual_seed(7 + rank)
+    pool = torch.empty(Np, D, dtype=torch.bfloat16, device=device)
+    step = 1 << 20
+    for lo in range(0, Np, step):
+        hi = min(Np, lo + step)
+        pool[lo:hi] = (torch.randn(hi - lo, D, device=device, generator=g) * 0.05).to(torch.bfloat16)
+    gq = torch.Generator(device=device).manual_seed(7)
+    queries = (torch.randn(Q, D, device=device, generator=gq) * 0.05).to(torch.bfloat16)
+    ws = torch.empty(K._lib.load().paced_pool_topk_workspace_bytes(Q, k), dtype=torch.uint8, device=device)
+
+    def once():
+        s, i = K.pool_topk(queries, pool, k, index_base=rank * Np, workspace=ws)
+        if world > 1:
+            gs = [torch.empty_like(s) for _ in range(world)]
+            gi = [torch.empty_like(i) for _ in range(world)]
+            dist.all_gather(gs, s)
+            dist.all_gather(gi, i)
+            s, i = K.topk_merge(torch.cat(gs, 1).contiguous(), torch.cat(gi, 1).contiguous(), k)
+        return s, i
+    once()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.mine_iters):
+        once()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / args.mine_iters
+    if world > 1:
+        t = torch.tensor([el], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    total_rows = Np * world
+    flops = 2.0 * Q * total_rows * D
+    bytes_alg = total_rows * D * 2 + Q * D * 2 + Q * k * 12
+    return {"metric": "negative-pool scores/sec", "value": Q * total_rows / el, "unit": "scores/s", "ms_per_sweep": el * 1e3,
+            "config": {"workload": f"top-{k} of {Q} queries x {total_rows} pool rows x {D} dims, bf16, pool sharded over {world} GPU(s)"},
+            "roofline": {"bound": "mfma", "achieved": flops / el / 1e12, "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": flops / el / (world * BF16_DENSE_PEAK), "hbm_frac": bytes_alg / el / (world * HBM_PEAK),
+                         "algorithmic_bytes": bytes_alg, "traffic": None}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="t5-base")
+    ap.add_argument("--batch", type=int, default=32, help="tuples per GPU")
+    ap.add_argument("--n_neg", type=int, default=16)
+    ap.add_argument("--seq", type=int, default=256)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=2)
+    ap.add_argument("--skip-mining", action="store_true")
+    ap.add_argument("--mine_pool", type=int, default=10_000_000)
+    ap.add_argument("--mine_queries", type=int, default=4096)
+    ap.add_argument("--mine_k", type=int, default=1000)
+    ap.add_argument("--mine_iters", type=int, default=2)
+    args = ap.parse_args()
+
+    from pacednegatives_amd.trainer import init_distributed
+    rank, world, local = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
+
+    out, model = run_train(args, rank, world, device)
+    dims = model.model.config
+    del model
+    torch.cuda.empty_cache()
+    if not args.skip_mining:
+        out["secondary"] = run_mining(args, rank, world, device)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, dims)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,10 @@ from . import _lib
 EPI_BF16, EPI_RES_DROP, EPI_RELU_DROP, EPI_MASK, EPI_F32, EPI_ATOMIC_F32 = range(6)
 BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
 
+# When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
+# ((trans_a, trans_b, epilogue), algorithmic FLOPs, start, end) is appended (bench.py's roofline leg).
+PROFILE = None
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -55,9 +59,16 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
         if tuple(aux.shape) != (M, N):
             raise ValueError("aux must have the shape of c")
         ldaux = _rows2d(aux, "aux")
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(lib.paced_gemm_bf16(_p(a), _p(b), _p(c), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
                                    int(trans_a), int(trans_b), epilogue, alpha, mask_scale, drop_p, drop_seed, splits,
                                    _stream()), "paced_gemm_bf16")
+    if prof is not None:
+        e1.record()
+        prof.append(((int(trans_a), int(trans_b), int(epilogue)), 2.0 * M * N * K, e0, e1))
     return c
 
 

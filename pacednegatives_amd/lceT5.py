@@ -1,0 +1,363 @@
+"""The lceT5 training step on MI355X (mirror of ``pacednegatives/lceT5.py``, Lightning-free).
+
+Same names, constructor arguments and step semantics as the reference module: ``LCEDataModule``
+(``lceT5.py:13-67``), ``ChangeDifficulty`` (``:77-80``), ``LCEWeights`` (``:82-99``), ``LCEModel``
+(``:101-182``) and the helpers ``batch_iter`` / ``concatenate``.  The arithmetic of a step -- four T5
+forwards, the per-token cross-entropy grouped into the LCE loss, the eta-thresholded weights and their
+meta-update, the backward pass and both AdamW updates -- runs in the HIP kernels of libpaced_hip.so.
+Data-parallel runs (one process per GPU) all-reduce the eta gradient and the flat fp32 gradient
+buffer over RCCL (``torch.distributed`` backend "nccl").
+"""
+from __future__ import annotations
+
+import itertools
+import json
+import math
+import os
+from collections import OrderedDict
+from typing import Any, List
+
+import torch
+
+from . import kernels as K
+from .dataloader import LCEDataset
+from .model import T5ForConditionalGenerationHIP
+from .tokenizer import load_tokenizer
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+class _HParams(dict):
+    """Dict with attribute access, as Lightning's ``self.hparams``."""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+# ----------------------------------------------------------------------------------------- data module
+class LCEDataModule:
+    def __init__(self, data_dir: str = "path/to/dir", corpus: Any = "msmarco-passage", tokenizer: Any = None,
+                 batch_size: int = 32, shuffle=False, use_max=False, var=0.01, n=2, init_weight=0. + 1e-10, num_workers=4):
+        self.data_dir = data_dir
+        if isinstance(corpus, str):
+            try:
+                import ir_datasets as irds
+            except ImportError as e:
+                raise ImportError("corpus was given by name but ir_datasets is not installed; pass an object with "
+                                  "docs_iter()/queries_iter() instead") from e
+            corpus = irds.load(corpus)
+        self.corpus = corpus
+        self.tokenizer = tokenizer
+        self.batch_size = batch_size
+        self.shuffle = shuffle
+        self.use_max = use_max
+        self.var = var
+        self.n = n
+        self.num_workers = num_workers
+        self.weight = init_weight
+
+    def collate(self):
+        """Reference ``lceT5.py:38-54``: tokenise positives and negatives separately, pad each to its own
+        longest, labels "true"/"false"; the attention masks are dropped."""
+        tokenizer = self.tokenizer
+
+        def collate_fn(batch):
+            pos = [x["pos"] for x in batch]
+            neg = list(itertools.chain(*[x["neg"] for x in batch]))
+            pos_t = tokenizer(pos, padding=True, return_tensors="pt")
+            neg_t = tokenizer(neg, padding=True, return_tensors="pt")
+            pos_l = tokenizer(["true"] * len(pos_t["input_ids"]), padding=True, return_tensors="pt")["input_ids"]
+            neg_l = tokenizer(["false"] * len(neg_t["input_ids"]), padding=True, return_tensors="pt")["input_ids"]
+            return ({"input_ids": pos_t["input_ids"], "labels": pos_l}, {"input_ids": neg_t["input_ids"], "labels": neg_l})
+        return collate_fn
+
+    def setup(self, stage: str = None):
+        with open(self.data_dir, "r") as f:
+            records = json.load(f)
+        if self.shuffle:
+            import random
+            random.shuffle(records)
+        self.pairs = [[str(r["query_id"]), str(r["doc_id_a"])] for r in records]
+        self.neg_idx = [[str(x) for x in r["doc_id_b"]] for r in records]
+        self.dataset = LCEDataset(self.pairs, self.neg_idx, self.corpus, self.tokenizer, self.weight, self.batch_size,
+                                  var=self.var, n=self.n, min=0. + 1e-10, max=1.0 - 1e-10, use_max=self.use_max)
+
+    def train_dataloader(self, rank: int = 0, world_size: int = 1):
+        """Sequential loader; with ``world_size`` > 1 rank r reads items r, r+W, ... (what Lightning's
+        non-shuffling DistributedSampler gives each rank); ``batch_size`` is per rank."""
+        from torch.utils.data import DataLoader, Subset
+        ds = self.dataset
+        view = ds if world_size == 1 else Subset(ds, list(range(rank, len(ds) - len(ds) % world_size, world_size)))
+        loader = DataLoader(view, batch_size=self.batch_size, num_workers=self.num_workers, collate_fn=self.collate(),
+                            pin_memory=torch.cuda.is_available())
+        loader.paced_dataset = ds
+        return loader
+
+
+def batch_iter(iterable, n=1):
+    l = len(iterable)
+    for ndx in range(0, l, n):
+        yield iterable[ndx:min(ndx + n, l)]
+
+
+def concatenate(*lists):
+    return list(itertools.chain(*lists))
+
+
+class ChangeDifficulty:
+    """Reference ``lceT5.py:77-80``: before every batch the dataset's pace becomes min(1-1e-10, eta).
+    (With worker processes the workers' dataset copies do not see the write, in the reference as here.)"""
+
+    def on_train_batch_start(self, trainer, pl_module, batch, batch_idx):
+        loader = trainer.train_dataloader
+        ds = getattr(loader, "paced_dataset", None) or loader.dataset
+        ds.weight = min(1 - 1e-10, pl_module.difficulty)
+
+
+# ------------------------------------------------------------------------------------------- weights
+class LCEWeights:
+    """eta-thresholded difficulty weights (reference ``lceT5.py:82-99``): w_i = loss_i/eta where
+    loss_i <= eta, else 0.  ``eta`` is a 1-element fp32 device tensor updated by the meta optimiser."""
+
+    def __init__(self, hparams, device="cuda"):
+        eta0 = hparams["eta"] if isinstance(hparams, dict) else hparams.eta
+        self.device = torch.device(device)
+        self.eta = torch.tensor([float(eta0)], dtype=F32, device=self.device)
+        self.eta_grad = torch.zeros(4, dtype=F32, device=self.device)      # [0] holds d meta_loss / d eta
+        self.stats = torch.zeros(4, dtype=F32, device=self.device)         # mean w, mean w*loss, d/d eta, mean loss
+
+    def parameters(self):
+        return [self.eta]
+
+    def weighting(self, x, y):
+        return x / y
+
+    def forward(self, loss: torch.Tensor) -> torch.Tensor:
+        loss = loss.to(self.device, F32).contiguous()
+        w = torch.empty_like(loss)
+        K.lce_weights(loss, self.eta, w, self.stats)
+        self.eta_grad[0:1].copy_(self.stats[2:3])
+        return w
+
+    __call__ = forward
+
+
+# ---------------------------------------------------------------------------------------- optimisers
+class FusedAdamW:
+    """transformers.AdamW semantics (betas .9/.999, eps 1e-6, weight_decay 0, bias-corrected) as one
+    kernel over a flat fp32 buffer; see ``paced_adamw`` in include/paced_hip.h."""
+
+    def __init__(self, p32, g32, m, v, p16=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0):
+        self.p32, self.g32, self.m, self.v, self.p16 = p32, g32, m, v, p16
+        self.base_lr = self.lr = lr
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.t = 0
+        self.param_groups = [{"lr": lr}]
+
+    def zero_grad(self):
+        self.g32.zero_()
+
+    def step(self, grad_scale: float = 1.0):
+        self.t += 1
+        b1, b2 = self.betas
+        lr = self.param_groups[0]["lr"]
+        step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        K.adamw(self.p32, self.g32, self.m, self.v, self.p16, beta1=b1, beta2=b2, eps=self.eps, step_size=step_size,
+                decay=lr * self.weight_decay, grad_scale=grad_scale)
+
+
+class LinearWarmupSchedule:
+    """``get_linear_schedule_with_warmup`` (formula restated in the reference at ``pairwrapper.py:16-25``):
+    a LambdaLR, so the optimiser starts at base_lr * lambda(0) and each ``step()`` moves to lambda(k)."""
+
+    def __init__(self, optimizer: FusedAdamW, num_warmup_steps: int, num_training_steps: int):
+        self.opt, self.warm, self.total, self.k = optimizer, num_warmup_steps, num_training_steps, 0
+        self._apply()
+
+    def multiplier(self, k: int) -> float:
+        if k < self.warm:
+            return float(k) / float(max(1, self.warm))
+        return max(0.0, float(self.total - k) / float(max(1, self.total - self.warm)))
+
+    def _apply(self):
+        self.opt.param_groups[0]["lr"] = self.opt.base_lr * self.multiplier(self.k)
+
+    def step(self):
+        self.k += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [self.opt.param_groups[0]["lr"]]
+
+
+# --------------------------------------------------------------------------------------------- model
+class LCEModel:
+    def __init__(self, hparams, device=None):
+        self.hparams = _HParams()
+        for key in hparams.keys():
+            self.hparams[key] = hparams[key]
+        if not torch.cuda.is_available():
+            raise RuntimeError("LCEModel runs its arithmetic in HIP kernels and needs a GPU (no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        seed = int(self.hparams.get("seed", 0) or 0)
+        self.model = T5ForConditionalGenerationHIP.from_pretrained(self.hparams.model_name, device=self.device, seed=seed)
+        self.tokenizer = load_tokenizer(self.hparams.model_name, self.model.config.vocab_size)
+        self.weights = LCEWeights(self.hparams, device=self.device)
+        self._eta_m = torch.zeros(4, dtype=F32, device=self.device)
+        self._eta_v = torch.zeros(4, dtype=F32, device=self.device)
+        self._eta_p = torch.zeros(4, dtype=F32, device=self.device)     # 16-byte aligned home of eta
+        self._eta_p[0:1].copy_(self.weights.eta)
+        self.weights.eta = self._eta_p[0:1]
+        self.automatic_optimization = False
+        self.dropout = self.hparams.get("dropout", None)
+        if self.dropout is None:
+            self.dropout = self.model.config.dropout_rate            # Lightning trains in train mode
+        self.share_forward = bool(self.hparams.get("share_forward", False))
+        self.difficulty = float(self.weights.eta.item())
+        self.global_step = 0
+        self.logged = OrderedDict()
+        self._opts = None
+        self._base_seed = int(self.hparams.get("dropout_seed", 1234) or 1234)
+
+    # ---- Lightning-like plumbing
+    def log(self, name, value):
+        self.logged[name] = value
+
+    def optimizers(self):
+        if self._opts is None:
+            self._opts = self.configure_optimizers()
+        return self._opts[0]
+
+    def lr_schedulers(self):
+        if self._opts is None:
+            self._opts = self.configure_optimizers()
+        return self._opts[1]
+
+    def configure_optimizers(self):
+        """Reference ``lceT5.py:170-182``: AdamW(eta, lr=meta_lr), AdamW(T5, lr=lr), two linear schedules."""
+        P = self.model.params
+        meta_opt = FusedAdamW(self._eta_p, self.weights.eta_grad, self._eta_m, self._eta_v, None, lr=self.hparams.meta_lr)
+        opt = FusedAdamW(P.p32, P.g32, P.m, P.v, P.p16, lr=self.hparams.lr)
+        meta_sched = LinearWarmupSchedule(meta_opt, self.hparams.warmup_steps, self.hparams.total_steps)
+        sched = LinearWarmupSchedule(opt, self.hparams.warmup_steps, self.hparams.total_steps)
+        return [meta_opt, opt], [meta_sched, sched]
+
+    # ---- loss
+    def _token_ce(self, logits2d, labels, dlogits=None, gscale=1.0):
+        loss = torch.empty(logits2d.shape[0], dtype=F32, device=self.device)
+        K.cross_entropy(logits2d, labels.to(self.device, torch.int64).contiguous().view(-1), loss, dlogits,
+                        ignore_index=int(self.hparams.ignore_index), gscale=gscale)
+        return loss
+
+    def pair_loss(self, p, n, op, on):
+        """Reference ``lceT5.py:116-123``.  p [B,T,V]; n [*, n_neg, V] (the caller's view) or [B*n_neg,T,V];
+        returns the [B*T] LCE rows: row r = pce[r] + sum|mean of nce[r*n_neg:(r+1)*n_neg]."""
+        V = p.shape[-1]
+        pce = self._token_ce(p.reshape(-1, V).to(self.device, F32).contiguous(), op)
+        nce = self._token_ce(n.reshape(-1, V).to(self.device, F32).contiguous(), on)
+        ce = torch.empty_like(pce)
+        K.lce_group(pce, nce, ce, int(self.hparams.n), bool(self.hparams.use_mean))
+        return ce
+
+    # ---- the step
+    def _forward_pair(self, p, n, save, call):
+        """Run the positive and negative batches; one packed call when their lengths agree."""
+        eng = self.model.engine
+        seed = (self._base_seed * 0x9E3779B1 + self.global_step * 8 + call) & 0xFFFFFFFF
+        B = p["input_ids"].shape[0]
+        if p["input_ids"].shape[1] == n["input_ids"].shape[1]:
+            ids = torch.cat([p["input_ids"].to(self.device), n["input_ids"].to(self.device)], 0)
+            lab = torch.cat([p["labels"].to(self.device), n["labels"].to(self.device)], 0)
+            st = eng.forward(ids, lab, save=save, drop_p=self.dropout, seed=seed)
+            return [st], st.logits[:2 * B], st.logits[2 * B:]
+        sp = eng.forward(p["input_ids"], p["labels"], save=save, drop_p=self.dropout, seed=seed)
+        sn = eng.forward(n["input_ids"], n["labels"], save=save, drop_p=self.dropout, seed=seed ^ 0x55555555)
+        return [sp, sn], sp.logits, sn.logits
+
+    def training_step(self, batch, batch_nb):
+        """Reference ``lceT5.py:125-168``, in the same order."""
+        p, n = batch
+        hp = self.hparams
+        nneg, use_mean = int(hp.n), bool(hp.use_mean)
+        meta_opt, opt = self.optimizers()
+        meta_scheduler, scheduler = self.lr_schedulers()
+        dist = _dist()
+        world = dist.get_world_size() if dist else 1
+        B = p["input_ids"].shape[0]
+        if n["input_ids"].shape[0] != B * nneg:
+            raise ValueError(f"negative batch has {n['input_ids'].shape[0]} rows, expected batch*n = {B * nneg}")
+        plab = p["labels"].to(self.device, torch.int64).contiguous().view(-1)
+        nlab = n["labels"].to(self.device, torch.int64).contiguous().view(-1)
+        ign = int(hp.ignore_index)
+
+        # (a) no-grad forwards and the LCE rows                                             :131-135
+        states, plog, nlog = self._forward_pair(p, n, save=False, call=0)
+        pce = torch.empty(2 * B, dtype=F32, device=self.device)
+        nce = torch.empty(2 * B * nneg, dtype=F32, device=self.device)
+        K.cross_entropy(plog, plab, pce, None, ignore_index=ign)
+        K.cross_entropy(nlog, nlab, nce, None, ignore_index=ign)
+        loss = torch.empty(2 * B, dtype=F32, device=self.device)
+        K.lce_group(pce, nce, loss, nneg, use_mean)
+        del states, plog, nlog
+
+        # (b) weights and the meta update of eta                                            :137-143
+        weights = self.weights(loss)
+        meta_opt_grad = self.weights.eta_grad
+        stats = self.weights.stats.clone()
+        if dist:
+            dist.all_reduce(meta_opt_grad)                      # sum over ranks; averaged by grad_scale below
+        meta_opt.step(grad_scale=1.0 / world)
+        meta_scheduler.step()
+
+        # (d) forwards with state, loss, backward, main update                              :149-157
+        R = 2 * B
+        g_pos = 1.0 / R
+        g_neg = (1.0 / R) * ((1.0 / nneg) if use_mean else 1.0)
+        if self.share_forward and self.dropout == 0.0:
+            raise NotImplementedError("share_forward is reserved for a later round")
+        states, plog, nlog = self._forward_pair(p, n, save=True, call=1)
+        V = plog.shape[1]
+        pce2 = torch.empty(2 * B, dtype=F32, device=self.device)
+        nce2 = torch.empty(2 * B * nneg, dtype=F32, device=self.device)
+        if len(states) == 1:
+            dl = torch.empty(states[0].logits.shape, dtype=BF16, device=self.device)
+            K.cross_entropy(plog, plab, pce2, dl[:2 * B], ignore_index=ign, gscale=g_pos)
+            K.cross_entropy(nlog, nlab, nce2, dl[2 * B:], ignore_index=ign, gscale=g_neg)
+            states[0].logits = None
+            self.model.engine.backward(states[0], dl)
+        else:
+            dlp = torch.empty(plog.shape, dtype=BF16, device=self.device)
+            K.cross_entropy(plog, plab, pce2, dlp, ignore_index=ign, gscale=g_pos)
+            self.model.engine.backward(states[0], dlp)
+            dln = torch.empty(nlog.shape, dtype=BF16, device=self.device)
+            K.cross_entropy(nlog, nlab, nce2, dln, ignore_index=ign, gscale=g_neg)
+            self.model.engine.backward(states[1], dln)
+        main_loss = torch.empty(2 * B, dtype=F32, device=self.device)
+        K.lce_group(pce2, nce2, main_loss, nneg, use_mean)
+        del states, plog, nlog
+        if dist:
+            dist.all_reduce(self.model.params.g32)
+        opt.step(grad_scale=1.0 / world)
+        scheduler.step()
+        opt.zero_grad()
+
+        # one host read-back per step: stats of (b), eta after the meta update, mean main loss
+        host = torch.cat([stats, self.weights.eta, main_loss.mean().view(1)]).tolist()
+        avg_weight, meta_loss_mean, _deta, loss_mean, eta, main_mean = host
+        self.log("avg_weight", avg_weight)
+        self.log("meta_loss", meta_loss_mean)
+        self.log("eta", eta)
+        self.log("main_loss", loss_mean)          # the reference logs the no-grad loss under this name (:166)
+        self.log("lr-AdamW", scheduler.get_last_lr()[0])
+        self.log("lr-AdamW-meta", meta_scheduler.get_last_lr()[0])
+        self.difficulty = eta
+        self.global_step += 1
+        tqdm_dict = {"meta_loss": loss_mean, "avg_weight": avg_weight, "main_loss": loss_mean}
+        return OrderedDict({"main_loss": main_mean, "meta_loss": meta_loss_mean, "progress_bar": tqdm_dict, "log": tqdm_dict,
+                            "loss_rows": loss, "weights": weights, "main_loss_rows": main_loss})

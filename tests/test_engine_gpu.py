@@ -1,0 +1,178 @@
+"""End-to-end parity of the HIP T5 engine and the lceT5 step against the CPU oracle and the committed
+fixtures recorded from Hugging Face T5 / the reference.  Tolerances: the HIP path stores activations
+in bf16 (8 significant bits); against the oracle run with bf16 rounding at the same points the
+difference is accumulation order only (1e-3-class); against the fp32 fixtures it is the bf16 storage
+error itself (a few 1e-2 of the logit scale)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lce_ref  # noqa: E402
+from oracle.t5_ref import T5Dims as RefDims, init_params, t5_forward  # noqa: E402
+from pacednegatives_amd.config import NAMED  # noqa: E402
+
+TINY = NAMED["t5-tiny"]
+RTINY = RefDims(TINY.vocab_size, TINY.d_model, TINY.d_kv, TINY.num_heads, TINY.d_ff, TINY.num_layers, TINY.num_decoder_layers)
+
+
+def make_model(seed=0):
+    from pacednegatives_amd.model import T5ForConditionalGenerationHIP
+    m = T5ForConditionalGenerationHIP(TINY, device="cuda", init=False)
+    P = init_params(RTINY, seed)
+    m.params.load_hf(P)
+    return m, P
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_forward_logits_vs_hf_fixture_and_oracle(golden_dir, ci):
+    g = np.load(os.path.join(golden_dir, "t5_forward.npz"))
+    ids, labels = torch.from_numpy(g[f"t5_ids{ci}"]), torch.from_numpy(g[f"t5_labels{ci}"])
+    m, P = make_model()
+    m.eval()
+    got = m(input_ids=ids, labels=labels).logits.cpu()
+    hf = torch.from_numpy(g[f"t5_logits{ci}"])
+    emu = t5_forward(P, RTINY, ids, labels, emulate_bf16=True)
+    scale = hf.abs().max().item()
+    assert (got - emu).abs().max().item() < 6e-3 * scale, "vs oracle with bf16 rounding at the same points"
+    assert (got - hf).abs().max().item() < 5e-2 * scale, "vs Hugging Face fp32 logits (bf16 storage error)"
+    # the loss the step consumes: within 1e-3 relative of the bf16-emulating oracle, 1e-2 of fp32
+    ce = lambda lg: torch.nn.functional.cross_entropy(lg.view(-1, lg.shape[-1]), labels.view(-1), reduction="none")  # noqa: E731
+    np.testing.assert_allclose(ce(got).numpy(), ce(emu).numpy(), rtol=2e-3)
+    np.testing.assert_allclose(ce(got).numpy(), ce(hf).numpy(), rtol=1e-2)
+
+
+def test_forward_is_batch_invariant():
+    m, _ = make_model()
+    m.eval()
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(2, TINY.vocab_size, (5, 40), generator=g)
+    labels = torch.tensor([[1176, 1]] * 5)
+    full = m(input_ids=ids, labels=labels).logits
+    one = m(input_ids=ids[3:4], labels=labels[3:4]).logits
+    assert torch.equal(full[3:4], one)
+
+
+@pytest.mark.parametrize("S", [24, 70])
+def test_backward_gradients_vs_oracle(S):
+    m, P = make_model()
+    B = 3
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(2, TINY.vocab_size, (B, S), generator=g)
+    labels = torch.tensor([[6136, 1]] * B)
+    st = m.engine.forward(ids, labels, save=True, drop_p=0.0, seed=1)
+    from pacednegatives_amd import kernels as K
+    loss = torch.empty(B * 2, device="cuda")
+    dl = torch.empty(B * 2, TINY.vocab_size, device="cuda", dtype=torch.bfloat16)
+    K.cross_entropy(st.logits, labels.cuda().view(-1).contiguous(), loss, dl, gscale=1.0 / (B * 2))
+    m.params.g32.zero_()
+    m.engine.backward(st, dl)
+    torch.cuda.synchronize()
+    got = {k: v.cpu() for k, v in m.params.to_hf("grad").items()}
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lg = t5_forward(leaves, RTINY, ids, labels, emulate_bf16=True)
+    torch.nn.functional.cross_entropy(lg.view(-1, lg.shape[-1]), labels.view(-1), reduction="mean").backward()
+    worst = 0.0
+    for k, v in leaves.items():
+        want = v.grad if v.grad is not None else torch.zeros_like(v)
+        denom = want.abs().max().item() + 1e-8
+        err = (got[k] - want).abs().max().item() / denom
+        worst = max(worst, err)
+        # gradients flow through bf16 activations: 3e-2 of each tensor's own scale
+        assert err < 3e-2, (k, err, denom)
+    assert worst > 0
+
+
+@pytest.mark.parametrize("use_mean", [False, True])
+def test_training_steps_vs_oracle_and_reference_fixture(golden_dir, use_mean):
+    from pacednegatives_amd.lceT5 import LCEModel
+    g = np.load(os.path.join(golden_dir, "train_step.npz"))
+    B, n, S, warm, total = [int(x) for x in g["hparams"]]
+    eta0, lr = [float(x) for x in g["eta0_lr"]]
+    pos, plab, neg, nlab = (torch.from_numpy(g[k]) for k in ("pos", "plab", "neg", "nlab"))
+    hp = {"model_name": "t5-tiny", "total_steps": total, "eta": eta0, "batch_size": B, "lr": lr, "meta_lr": lr, "n": n,
+          "warmup_steps": warm, "use_mean": use_mean, "ignore_index": -100, "dropout": 0.0}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = LCEModel(hp)
+    P = init_params(RTINY, 0)
+    model.model.params.load_hf(P)
+    eta = torch.tensor([eta0])
+    opt, meta = lce_ref.HFAdamW(P, lr), lce_ref.HFAdamW({"eta": eta}, lr)
+    tag = f"step_um{int(use_mean)}_"
+    batch = ({"input_ids": pos, "labels": plab}, {"input_ids": neg, "labels": nlab})
+    for it in range(3):
+        out = model.training_step(batch, it)
+        ref = lce_ref.training_step(P, RTINY, eta, opt, meta, it, pos, plab, neg, nlab, n, use_mean, warm, total, emulate_bf16=True)
+        rows = out["loss_rows"].cpu().numpy()
+        # vs the oracle with bf16 rounding at the same points
+        np.testing.assert_allclose(rows, ref["loss"].numpy(), rtol=5e-3)
+        np.testing.assert_allclose(out["main_loss_rows"].cpu().numpy(), ref["main_loss"].numpy(), rtol=5e-3)
+        np.testing.assert_allclose(out["weights"].cpu().numpy(), ref["weights"].numpy(), rtol=5e-3, atol=1e-6)
+        assert abs(model.difficulty - float(eta)) < 2e-5
+        # vs the fixture recorded from the reference's own pair_loss / LCEWeights on HF T5 in fp32
+        np.testing.assert_allclose(rows, g[tag + f"loss{it}"], rtol=2e-2)
+        if it == 0:
+            np.testing.assert_allclose(model.difficulty, float(g[tag + "eta0"][0]), rtol=1e-5)
+    w = model.model.params.master("enc.0.qkv")[:TINY.inner].cpu()
+    w_ref = P["encoder.block.0.layer.0.SelfAttention.q.weight"]
+    # three AdamW updates of size <= lr each; sign flips of tiny gradients are the only divergence
+    assert (w - w_ref).abs().max().item() <= 2.1 * lr
+    assert ((w - w_ref).abs() > 0.5 * lr).float().mean().item() < 0.05
+
+
+def test_unequal_lengths_take_the_two_call_path():
+    from pacednegatives_amd.lceT5 import LCEModel
+    hp = {"model_name": "t5-tiny", "total_steps": 10, "eta": 20.0, "batch_size": 2, "lr": 1e-3, "meta_lr": 1e-3, "n": 3,
+          "warmup_steps": 0, "use_mean": False, "ignore_index": -100, "dropout": 0.0}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = LCEModel(hp)
+    P = init_params(RTINY, 0)
+    model.model.params.load_hf(P)
+    g = torch.Generator().manual_seed(3)
+    pos = torch.randint(2, TINY.vocab_size, (2, 19), generator=g)
+    neg = torch.randint(2, TINY.vocab_size, (6, 33), generator=g)
+    batch = ({"input_ids": pos, "labels": torch.tensor([[1176, 1]] * 2)}, {"input_ids": neg, "labels": torch.tensor([[6136, 1]] * 6)})
+    out = model.training_step(batch, 0)
+    eta = torch.tensor([20.0])
+    ref = lce_ref.training_step(P, RTINY, eta, lce_ref.HFAdamW(P, 1e-3), lce_ref.HFAdamW({"eta": eta}, 1e-3), 0,
+                                pos, batch[0]["labels"], neg, batch[1]["labels"], 3, False, 0, 10, emulate_bf16=True)
+    np.testing.assert_allclose(out["loss_rows"].cpu().numpy(), ref["loss"].numpy(), rtol=5e-3)
+    np.testing.assert_allclose(out["main_loss_rows"].cpu().numpy(), ref["main_loss"].numpy(), rtol=5e-3)
+
+
+def test_dropout_step_runs_and_is_seed_deterministic():
+    from pacednegatives_amd.lceT5 import LCEModel
+    from pacednegatives_amd.synthetic import token_batch
+    rows = []
+    for _ in range(2):
+        hp = {"model_name": "t5-tiny", "total_steps": 10, "eta": 20.0, "batch_size": 2, "lr": 1e-3, "meta_lr": 1e-3, "n": 2,
+              "warmup_steps": 0, "use_mean": False, "ignore_index": -100, "dropout": 0.1, "dropout_seed": 77}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = LCEModel(hp)
+        out = model.training_step(token_batch(2, 2, 32, TINY.vocab_size), 0)
+        rows.append(out["main_loss_rows"].cpu())
+        assert torch.isfinite(rows[-1]).all()
+    assert torch.equal(rows[0], rows[1])
+
+
+def test_save_pretrained_round_trip(tmp_path):
+    from pacednegatives_amd.model import T5ForConditionalGenerationHIP
+    m, P = make_model(3)
+    m.save_pretrained(str(tmp_path / "ckpt"))
+    m2 = T5ForConditionalGenerationHIP.from_pretrained(str(tmp_path / "ckpt"))
+    for (k, a), (k2, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k == k2 and torch.equal(a, b)
+    assert set(m.state_dict()) == set(P)
+
+
+def test_smoke_entry():
+    from pacednegatives_amd.selftest import smoke_step
+    assert smoke_step(verbose=False) < 1e-2

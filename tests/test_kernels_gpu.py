@@ -118,7 +118,10 @@ def test_gemm_dropout_matches_mask_function():
     assert torch.equal(out.float(), (acc.clamp_min(0) * mask).to(torch.bfloat16).float())
     res = bf(ints((M, N), -9, 9, 14))
     K.gemm(bf(a), bf(b), out, epilogue=K.EPI_RES_DROP, aux=res, drop_p=p, drop_seed=seed)
-    assert torch.equal(out.float(), (res.float() + acc * mask).to(torch.bfloat16).float())
+    # the kernel may contract res + acc*factor into one fma (one rounding instead of two): allow 1 bf16 ulp
+    want = res.float() + acc * mask
+    assert ((out.float() - want).abs() <= want.abs() * 2 ** -7 + 1e-6).all()
+    assert torch.equal((out.float() == res.float()), (mask == 0) | (acc == 0))
     y = torch.empty(M * N, device=DEV, dtype=torch.bfloat16)
     x = bf(acc.cpu().reshape(-1))
     K.dropout_apply(x, y, drop_p=p, drop_seed=seed)
