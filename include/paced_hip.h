@@ -54,6 +54,10 @@ int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
                     int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
                     float drop_p, uint32_t drop_seed, int splits, void* stream);
 
+/* Tile selection of paced_gemm_bf16: 0 = heuristic (default), 128 = 128x128 tiles, 256 = 256x256
+ * double-buffered tiles.  Process-wide; meant for benchmarking and tests. */
+int paced_gemm_set_tile(int tile);
+
 /* ---- T5LayerNorm (RMS norm), HF:59-72; backward reached from lceT5.py:155 ------------------
  * fwd: y = bf16(x * rsqrt(mean(x^2)+eps) * w * out_scale) then dropout; rstd[M] saved (may be NULL).
  *      out_scale = d_model^-0.5 folds the tied-head rescale HF:1044-1045 into the final decoder norm.
@@ -79,19 +83,22 @@ int paced_cast_f32_bf16(const float* x, void* y, size_t n, void* stream);
 
 /* ---- relative position bias, HF:264-279 ------------------------------------------------------
  * tbl[h][i] = rel_bias[bucket[i]][h], i = key - query + (L-1)/2 for the encoder (L = 2S-1); the
- * bucket of every offset (HF:217-262) is computed on the host.  bwd scatters dtbl back (atomics). */
+ * bucket of every offset (HF:217-262) is computed on the host.  bwd sums `replicas` copies of dtbl
+ * ([replicas, H, L], see paced_enc_attn_bwd) and scatters the sum back (atomics). */
 int paced_relbias_table_fwd(const void* rel_bias, const int* bucket, float* tbl, int H, int L, void* stream);
-int paced_relbias_table_bwd(const float* dtbl, const int* bucket, float* drel_bias, int H, int L, void* stream);
+int paced_relbias_table_bwd(const float* dtbl, int replicas, const int* bucket, float* drel_bias, int H, int L, void* stream);
 
 /* ---- encoder self-attention, HF:144-173 with scaling = 1.0 (HF:196-197), no mask (lceT5.py:53) ----
  * q,k,v: rows (n*S+s), head h at columns [h*64, h*64+64), row stride ld.  ctx [N*S, ldo];
  * lse [N,H,S] fp32 (log-sum-exp of the biased scores); bias_tbl [H, 2S-1] fp32 or NULL.
- * bwd writes dq, dk, dv (same addressing, row stride ldd) and adds into dbias_tbl (may be NULL). */
+ * bwd writes dq, dk, dv (same addressing, row stride ldd) and adds into dbias_tbl (may be NULL):
+ * [dbias_replicas, H, 2S-1]; workgroups spread their adds over the replicas so that same-address
+ * atomics do not serialise; the caller sums the replicas (paced_relbias_table_bwd does). */
 int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, void* ctx, int ldo, float* lse,
                        const float* bias_tbl, int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
 int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* ctx, int ldo,
                        const void* dctx, int lddo, const float* lse, const float* bias_tbl,
-                       void* dq, void* dk_, void* dv, int ldd, float* dbias_tbl,
+                       void* dq, void* dk_, void* dv, int ldd, float* dbias_tbl, int dbias_replicas,
                        int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ---- decoder attention for the 2-token target, HF:459-498 ---------------------------------------

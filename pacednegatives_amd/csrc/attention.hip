@@ -62,7 +62,8 @@ struct AttnArgs {
     bf16* dq; bf16* dk; bf16* dv; int ldd;         // bwd outputs, same addressing as q/k/v
     float* lse;                                    // [N, H, S]
     const float* bias;                             // [H, 2S-1], index key - query + S - 1 (may be null)
-    float* dbias;                                  // [H, 2S-1] fp32 atomics (may be null)
+    float* dbias;                                  // [R, H, 2S-1] fp32 atomics, R replicas (may be null)
+    int dbias_replicas;
     int N, S, H;
     DropCfg drop;
 };
@@ -300,7 +301,9 @@ __global__ void __launch_bounds__(256) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * S - 1; i += 256) {
             const float v = ldb[i];
-            if (v != 0.f) atomicAdd(a.dbias + (size_t)h * (2 * S - 1) + i, v);
+            // every workgroup of a head adds to the same 2S-1 words; replicas keep same-address atomics apart
+            const int rep = (blockIdx.z * gridDim.x + blockIdx.x) % a.dbias_replicas;
+            if (v != 0.f) atomicAdd(a.dbias + ((size_t)rep * a.H + h) * (2 * S - 1) + i, v);
         }
     }
 }
@@ -632,7 +635,7 @@ extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, i
 
 extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* ctx, int ldo,
                                   const void* dctx, int lddo, const float* lse, const float* bias_tbl,
-                                  void* dq, void* dk_, void* dv, int ldd, float* dbias_tbl,
+                                  void* dq, void* dk_, void* dv, int ldd, float* dbias_tbl, int dbias_replicas,
                                   int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
     if (int e = check_common("paced_enc_attn_bwd", N, S, H, dk)) return e;
     PACED_CHECK_ARG(q && k && v && ctx && dctx && lse && dq && dk_ && dv, "paced_enc_attn_bwd: null operand");
@@ -641,7 +644,8 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
     a.o = (const bf16*)ctx; a.ldo = ldo; a.dout = (const bf16*)dctx; a.lddo = lddo;
     a.dq = (bf16*)dq; a.dk = (bf16*)dk_; a.dv = (bf16*)dv; a.ldd = ldd;
-    a.lse = const_cast<float*>(lse); a.bias = bias_tbl; a.dbias = dbias_tbl;
+    PACED_CHECK_ARG(!dbias_tbl || dbias_replicas >= 1, "paced_enc_attn_bwd: dbias_replicas must be >= 1");
+    a.lse = const_cast<float*>(lse); a.bias = bias_tbl; a.dbias = dbias_tbl; a.dbias_replicas = dbias_replicas;
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const dim3 grid((S + 127) / 128, H, N);
     const size_t smem1 = 16384 + (size_t)(64 + 2 * (2 * S + 160)) * 4;

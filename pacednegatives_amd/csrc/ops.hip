@@ -296,11 +296,13 @@ __global__ void relbias_table_fwd_kernel(const bf16* __restrict__ rel_bias, cons
     tbl[i] = bf2f(rel_bias[bucket[j] * H + h]);
 }
 __global__ void relbias_table_bwd_kernel(const float* __restrict__ dtbl, const int* __restrict__ bucket,
-                                         float* __restrict__ drel_bias, int H, int L) {
+                                         float* __restrict__ drel_bias, int H, int L, int replicas) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= H * L) return;
     const int h = i / L, j = i % L;
-    atomicAdd(drel_bias + bucket[j] * H + h, dtbl[i]);
+    float s = 0.f;
+    for (int r = 0; r < replicas; ++r) s += dtbl[(size_t)r * H * L + i];
+    atomicAdd(drel_bias + bucket[j] * H + h, s);
 }
 
 // -------------------------------------------------------------------------------------------- AdamW
@@ -449,9 +451,9 @@ extern "C" int paced_relbias_table_fwd(const void* rel_bias, const int* bucket, 
     return PACED_OK;
 }
 
-extern "C" int paced_relbias_table_bwd(const float* dtbl, const int* bucket, float* drel_bias, int H, int L, void* stream) {
-    PACED_CHECK_ARG(dtbl && bucket && drel_bias && H > 0 && L > 0, "paced_relbias_table_bwd: bad arguments");
-    hipLaunchKernelGGL(relbias_table_bwd_kernel, dim3((H * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, dtbl, bucket, drel_bias, H, L);
+extern "C" int paced_relbias_table_bwd(const float* dtbl, int replicas, const int* bucket, float* drel_bias, int H, int L, void* stream) {
+    PACED_CHECK_ARG(dtbl && bucket && drel_bias && H > 0 && L > 0 && replicas >= 1, "paced_relbias_table_bwd: bad arguments");
+    hipLaunchKernelGGL(relbias_table_bwd_kernel, dim3((H * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, dtbl, bucket, drel_bias, H, L, replicas);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }

@@ -72,6 +72,11 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
     return c
 
 
+def gemm_set_tile(tile: int):
+    """0 = heuristic, 128 or 256 = force that tile configuration (benchmarks and tests)."""
+    _lib.check(_lib.load().paced_gemm_set_tile(tile), "paced_gemm_set_tile")
+
+
 def rmsnorm_fwd(x, w, y, rstd=None, *, eps=1e-6, out_scale=1.0, drop_p=0.0, drop_seed=0):
     lib = _lib.load()
     _chk(x, BF16, "x"); _chk(w, BF16, "w"); _chk(y, BF16, "y"); _chk(rstd, F32, "rstd")
@@ -149,11 +154,13 @@ def relbias_table_fwd(rel_bias, bucket, tbl):
 
 
 def relbias_table_bwd(dtbl, bucket, drel_bias):
+    """dtbl is [H, L] or [replicas, H, L]; the replicas are summed."""
     lib = _lib.load()
     _chk(dtbl, F32, "dtbl"); _chk(bucket, I32, "bucket"); _chk(drel_bias, F32, "drel_bias")
-    H, L = dtbl.shape
+    reps = 1 if dtbl.dim() == 2 else dtbl.shape[0]
+    H, L = dtbl.shape[-2:]
     assert drel_bias.is_contiguous() and drel_bias.shape[1] == H and bucket.numel() == L and dtbl.is_contiguous()
-    _lib.check(lib.paced_relbias_table_bwd(_p(dtbl), _p(bucket), _p(drel_bias), H, L, _stream()), "paced_relbias_table_bwd")
+    _lib.check(lib.paced_relbias_table_bwd(_p(dtbl), reps, _p(bucket), _p(drel_bias), H, L, _stream()), "paced_relbias_table_bwd")
 
 
 def enc_attn_fwd(q, k, v, ctx, lse, bias_tbl, N, S, H, *, drop_p=0.0, drop_seed=0):
@@ -181,10 +188,13 @@ def enc_attn_bwd(q, k, v, ctx, dctx, lse, bias_tbl, dq, dk, dv, dbias_tbl, N, S,
     for t in (q, k, v, ctx, dctx, dq, dk, dv):
         assert tuple(t.shape) == (N * S, H * 64)
     assert lse.numel() == N * H * S and lse.is_contiguous()
-    for t in (bias_tbl, dbias_tbl):
-        assert t is None or (tuple(t.shape) == (H, 2 * S - 1) and t.is_contiguous())
+    assert bias_tbl is None or (tuple(bias_tbl.shape) == (H, 2 * S - 1) and bias_tbl.is_contiguous())
+    reps = 1
+    if dbias_tbl is not None:
+        assert dbias_tbl.is_contiguous() and tuple(dbias_tbl.shape[-2:]) == (H, 2 * S - 1) and dbias_tbl.dim() in (2, 3)
+        reps = 1 if dbias_tbl.dim() == 2 else dbias_tbl.shape[0]
     _lib.check(lib.paced_enc_attn_bwd(_p(q), _p(k), _p(v), ld, _p(ctx), _rows2d(ctx, "ctx"), _p(dctx), _rows2d(dctx, "dctx"),
-                                      _p(lse), _p(bias_tbl), _p(dq), _p(dk), _p(dv), ldd, _p(dbias_tbl),
+                                      _p(lse), _p(bias_tbl), _p(dq), _p(dk), _p(dv), ldd, _p(dbias_tbl), reps,
                                       N, S, H, 64, drop_p, drop_seed, _stream()), "paced_enc_attn_bwd")
 
 

@@ -143,20 +143,12 @@ class T5Engine:
     def _empty(self, rows, cols, dtype=BF16):
         return torch.empty(rows, cols, dtype=dtype, device=self.device)
 
-    @staticmethod
-    def _splits(out_rows: int, out_cols: int, contraction: int) -> int:
-        tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
-        ktiles = (contraction + 63) // 64
-        want = max(1, (1024 + tiles - 1) // tiles)
-        return max(1, min(want, ktiles))
-
     def _dweight(self, dy, x, name, rows: Optional[slice] = None):
         """grad[name] (+)= dy^T x  -- dy [M, out], x [M, in] -> [out, in], fp32 atomics."""
         g = self.params.grad(name)
         if rows is not None:
             g = g[rows]
-        K.gemm(dy, x, g, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32,
-               splits=self._splits(g.shape[0], g.shape[1], dy.shape[0]))
+        K.gemm(dy, x, g, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)   # 0: library picks the split
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids: torch.Tensor, labels: torch.Tensor, *, save: bool, drop_p: float = 0.0, seed: int = 0,
@@ -357,7 +349,7 @@ class T5Engine:
 
         # ---- encoder
         ne = dims.num_layers
-        dbias_tbl = torch.zeros(H, 2 * S - 1, dtype=F32, device=self.device)
+        dbias_tbl = torch.zeros(64, H, 2 * S - 1, dtype=F32, device=self.device)   # 64 replicas, summed at the end
         dh = self._empty(M, d)
         dz = self._empty(M, d) if masked_copy_needed() else None
         K.rmsnorm_bwd(d_enc, st.h_last, P.w("enc.final_ln"), st.rstd_ef, dh, dx2=dz, dw=P.grad("enc.final_ln"),

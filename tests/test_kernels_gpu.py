@@ -32,9 +32,16 @@ def rnd(shape, seed, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=[128, 256])
+def tile(request):
+    K.gemm_set_tile(request.param)
+    yield request.param
+    K.gemm_set_tile(0)
+
+
 @pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (300, 136, 128), (1, 8, 64), (257, 520, 192), (1000, 768, 256)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
-def test_gemm_exact_integers(M, N, K_, ta, tb):
+def test_gemm_exact_integers(M, N, K_, ta, tb, tile):
     if ta and M % 8:
         M = (M + 7) // 8 * 8
     Kc = K_ if not ta else K_ + 24          # ragged token contraction is allowed for transposed operands
@@ -51,7 +58,7 @@ def test_gemm_exact_integers(M, N, K_, ta, tb):
     assert torch.equal(c.cpu(), want)
 
 
-def test_gemm_strided_views_and_alpha():
+def test_gemm_strided_views_and_alpha(tile):
     a = ints((200, 128), -2, 2, 3)
     b = ints((72, 128), -2, 2, 4)
     Abig = bf(torch.cat([a, a + 1], dim=1))           # lda = 256, use the first 128 columns
@@ -63,7 +70,7 @@ def test_gemm_strided_views_and_alpha():
     assert (cbig[:, 72:] == 0).all()
 
 
-def test_gemm_epilogues():
+def test_gemm_epilogues(tile):
     M, N, Kc = 260, 256, 128
     a, b = ints((M, Kc), -2, 2, 5), ints((N, Kc), -2, 2, 6)
     res = ints((M, N), -20, 20, 7)
@@ -84,7 +91,7 @@ def test_gemm_epilogues():
 
 
 @pytest.mark.parametrize("splits", [1, 3, 8])
-def test_gemm_weight_gradient_atomic_split(splits):
+def test_gemm_weight_gradient_atomic_split(splits, tile):
     Mtok, No, Ko = 1000, 136, 192                     # dW[No,Ko] = dY[Mtok,No]^T X[Mtok,Ko]
     dy, x = ints((Mtok, No), -2, 2, 8), ints((Mtok, Ko), -2, 2, 9)
     c = torch.ones(No, Ko, device=DEV)
@@ -93,7 +100,7 @@ def test_gemm_weight_gradient_atomic_split(splits):
     assert torch.equal(c.cpu(), 1.0 + dy.t() @ x)
 
 
-def test_gemm_float_tolerance():
+def test_gemm_float_tolerance(tile):
     M, N, Kc = 512, 768, 3072
     a, b = rnd((M, Kc), 10), rnd((N, Kc), 11, Kc ** -0.5)
     A, B = bf(a), bf(b)
@@ -104,7 +111,7 @@ def test_gemm_float_tolerance():
     assert (c - want).abs().max().item() < 1e-4 * want.abs().max().item()
 
 
-def test_gemm_dropout_matches_mask_function():
+def test_gemm_dropout_matches_mask_function(tile):
     M, N, Kc = 192, 128, 64
     a, b = ints((M, Kc), -2, 2, 12), ints((N, Kc), -2, 2, 13)
     acc = (a @ b.t()).to(DEV)
@@ -236,9 +243,10 @@ def test_enc_attention_fwd_bwd(N, S, H, p):
     dctx = bf(rnd((N * S, I), 42))
     o_ref.backward(dctx.float())
     dqkv = torch.full((N * S, 3 * I), float("nan"), device=DEV, dtype=torch.bfloat16)
-    dtbl = torch.zeros_like(tbl)
-    K.enc_attn_bwd(q, k, v, ctx, dctx, lse, tbl, dqkv[:, :I], dqkv[:, I:2 * I], dqkv[:, 2 * I:], dtbl, N, S, H,
+    dtbl3 = torch.zeros(5, H, 2 * S - 1, device=DEV)        # replicated accumulator
+    K.enc_attn_bwd(q, k, v, ctx, dctx, lse, tbl, dqkv[:, :I], dqkv[:, I:2 * I], dqkv[:, 2 * I:], dtbl3, N, S, H,
                    drop_p=p, drop_seed=seed)
+    dtbl = dtbl3.sum(0)
     for got, want, name in ((dqkv[:, :I], ql.grad, "dq"), (dqkv[:, I:2 * I], kl.grad, "dk"), (dqkv[:, 2 * I:], vl.grad, "dv")):
         err = (got.float() - want).abs().max().item()
         assert err < 2.5e-2 * want.abs().max().item(), (name, err, want.abs().max().item())
@@ -368,6 +376,17 @@ def test_adamw_matches_hf_rule():
         pr = pr - step * mr / (vr.sqrt() + eps)
     np.testing.assert_allclose(p.cpu().numpy(), pr.float().numpy(), rtol=1e-5, atol=1e-6)
     assert torch.equal(pb, p.to(torch.bfloat16))
+
+
+def test_relbias_tables_replicas():
+    H, S = 2, 9
+    g = torch.Generator().manual_seed(98)
+    bucket = torch.randint(0, 32, (2 * S - 1,), generator=g).int().to(DEV)
+    dt = ints((3, H, 2 * S - 1), -2, 2, 99).to(DEV)
+    drel = torch.zeros(32, H, device=DEV)
+    K.relbias_table_bwd(dt, bucket, drel)
+    want = torch.zeros(32, H, device=DEV).index_add_(0, bucket.long(), dt.sum(0).t().contiguous())
+    assert torch.equal(drel, want)
 
 
 def test_relbias_tables():
