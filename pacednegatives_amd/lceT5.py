@@ -20,6 +20,7 @@ from typing import Any, List
 import torch
 
 from . import kernels as K
+from . import parallel
 from .dataloader import LCEDataset
 from .model import T5ForConditionalGenerationHIP
 from .tokenizer import load_tokenizer
@@ -33,11 +34,6 @@ class _HParams(dict):
 
     def __setattr__(self, k, v):
         self[k] = v
-
-
-def _dist():
-    import torch.distributed as dist
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
 # ----------------------------------------------------------------------------------------- data module
@@ -93,7 +89,7 @@ class LCEDataModule:
         non-shuffling DistributedSampler gives each rank); ``batch_size`` is per rank."""
         from torch.utils.data import DataLoader, Subset
         ds = self.dataset
-        view = ds if world_size == 1 else Subset(ds, list(range(rank, len(ds) - len(ds) % world_size, world_size)))
+        view = ds if world_size == 1 else Subset(ds, parallel.shard_indices(len(ds), rank, world_size))
         loader = DataLoader(view, batch_size=self.batch_size, num_workers=self.num_workers, collate_fn=self.collate(),
                             pin_memory=torch.cuda.is_available())
         loader.paced_dataset = ds
@@ -287,8 +283,7 @@ class LCEModel:
         nneg, use_mean = int(hp.n), bool(hp.use_mean)
         meta_opt, opt = self.optimizers()
         meta_scheduler, scheduler = self.lr_schedulers()
-        dist = _dist()
-        world = dist.get_world_size() if dist else 1
+        world = parallel.world_size()
         B = p["input_ids"].shape[0]
         if n["input_ids"].shape[0] != B * nneg:
             raise ValueError(f"negative batch has {n['input_ids'].shape[0]} rows, expected batch*n = {B * nneg}")
@@ -310,8 +305,7 @@ class LCEModel:
         weights = self.weights(loss)
         meta_opt_grad = self.weights.eta_grad
         stats = self.weights.stats.clone()
-        if dist:
-            dist.all_reduce(meta_opt_grad)                      # sum over ranks; averaged by grad_scale below
+        parallel.allreduce_sum_(meta_opt_grad)                  # sum over ranks; averaged by grad_scale below
         meta_opt.step(grad_scale=1.0 / world)
         meta_scheduler.step()
 
@@ -341,8 +335,7 @@ class LCEModel:
         main_loss = torch.empty(2 * B, dtype=F32, device=self.device)
         K.lce_group(pce2, nce2, main_loss, nneg, use_mean)
         del states, plog, nlog
-        if dist:
-            dist.all_reduce(self.model.params.g32)
+        parallel.allreduce_sum_(self.model.params.g32)          # one all-reduce over the flat fp32 gradient buffer
         opt.step(grad_scale=1.0 / world)
         scheduler.step()
         opt.zero_grad()
