@@ -88,7 +88,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
 
 // =================================================================================== forward
 // grid (ceil(S/128), H, N), 256 threads: wave w owns queries qb + 32w .. +32.
-__global__ void __launch_bounds__(256) enc_attn_fwd_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lK = smem;                 // 64 x 64 row image
     char* lV = smem + 8192;          // 64 x 64 tr image
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) enc_attn_fwd_kernel(AttnArgs a) {
 
 // ====================================================================== backward: dK, dV, dBias
 // grid (ceil(S/128), H, N): wave w owns keys kb + 32w .. +32 and sweeps all queries in tiles of 32.
-__global__ void __launch_bounds__(256) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lQr = smem;              // 32 x 64 row image of Q
     char* lQt = smem + 4096;       // tr image of Q
@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(256) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
 
+    float carry = 0.f;
     const int ntile = (S + 31) / 32;
     for (int qt = 0; qt < ntile; ++qt) {
         __syncthreads();
@@ -269,7 +270,27 @@ __global__ void __launch_bounds__(256) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             pd[r] = p * f;
             const float ds = p * (dp[r] * f - ldel[ql]);
             s[r] = ds;
-            if (a.dbias && ok) atomicAdd(&ldb[keyc - qq + S - 1], ds);
+        }
+        if (a.dbias) {
+            // Bias gradient = sums of dS along diagonals (key - query = const).  Rotate row ql of the
+            // 32x32 tile left by ql lanes (ds_bpermute): lane j then holds the element of diagonal
+            // j (no wrap) or j-32 (wrapped); two running sums per lane cover the tile's 63 diagonals.
+            // The wrapped half of this tile and the unwrapped half of the next query tile are the same
+            // diagonals, so it is carried in a register and each diagonal costs ONE LDS atomic in all.
+            float Ps = 0.f, Ns = 0.f;
+            const int j = lane & 31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = acc_row(r, hh);
+                const float v = __shfl(s[r], (hh << 5) | ((j + ql) & 31), 64);
+                if (j + ql < 32) Ps += v; else Ns += v;
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the live range: 4 permutes in flight
+            }
+            Ps += __shfl_xor(Ps, 32, 64);
+            Ns += __shfl_xor(Ns, 32, 64);
+            const int idx = (blockIdx.x * 128 + w * 32 + j) - qt * 32 + S - 1;      // diagonal base + j
+            if (hh == 0 && idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], Ps + carry);
+            carry = Ns;
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -298,6 +319,8 @@ __global__ void __launch_bounds__(256) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
         }
     }
     if (a.dbias) {
+        const int idx = (blockIdx.x * 128 + w * 32 + (lane & 31)) - (ntile - 1) * 32 - 32 + S - 1;   // wrapped half of the last tile
+        if (hh == 0 && idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], carry);
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * S - 1; i += 256) {
             const float v = ldb[i];
@@ -310,7 +333,7 @@ __global__ void __launch_bounds__(256) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
 
 // ================================================================================ backward: dQ
 // grid (ceil(S/128), H, N): wave w owns queries qb + 32w .. +32 and sweeps all keys in tiles of 64.
-__global__ void __launch_bounds__(256) enc_attn_bwd_dq_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(256, 3) enc_attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lKr = smem;               // 64 x 64 row image of K
     char* lKt = smem + 8192;        // tr image of K

@@ -120,6 +120,29 @@ struct TileOps {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_PTR(lB + (i * NW + w) * 1024), 16, offB[i], sB, 0, 0);
     }
 
+    // fragments of half a K step (k = 32*kk .. +32) from LDS buffer `buf`
+    static __device__ __forceinline__ void read_frags(const char* smem, int buf, int kk, int wm, int wn, int lane,
+                                                      bf16x8 (&fa)[MI], bf16x8 (&fb)[NJ]) {
+        const char* lA = smem + buf * BUF_BYTES;
+        const char* lB = lA + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = read_frag<TB, BN>(lB, wn * TN + j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = read_frag<TA, BM>(lA, wm * TM + i * 16, kk, lane);
+    }
+    template <bool NATURAL>
+    static __device__ __forceinline__ void mfma_block(const bf16x8 (&fa)[MI], const bf16x8 (&fb)[NJ], f32x4 (&acc)[MI][NJ]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (NATURAL) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
     // multiply the K step held in LDS buffer `buf` into the accumulators
     template <bool NATURAL>
     static __device__ __forceinline__ void multiply(const char* smem, int buf, int wm, int wn, int lane, f32x4 (&acc)[MI][NJ]) {
@@ -293,9 +316,20 @@ __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_bf16_kernel(Gem
         return;
     }
 
+    // ---- two LDS buffers, two fragment register sets, one barrier per K step placed MID-step:
+    //   phase A: MFMA(set0 = first half of tile t)  ||  ds_read set1 = second half of tile t
+    //   wait own LDS reads + own LDS-DMA, barrier     -> tile t+1 has landed, nobody reads buf[cur] any more
+    //   issue LDS-DMA of tile t+2 into buf[cur]
+    //   phase B: MFMA(set1)  ||  ds_read set0 = first half of tile t+1 (from buf[cur^1])
+    // so fragment reads and the DMA always run under MFMAs.  "tile t+1 / t+2" continue into the next
+    // work item (every item has at least two K steps: checked on the host), whose first tiles are
+    // therefore already in flight while this item's epilogue stores drain.
+    bf16x8 fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
     Ops::stage(smem, 0, (uint32_t)it.kbeg * kstrideA, (uint32_t)it.kbeg * kstrideB, w, it.rA, it.rB, offA, offB);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    Ops::stage(smem, 1, (uint32_t)(it.kbeg + BK) * kstrideA, (uint32_t)(it.kbeg + BK) * kstrideB, w, it.rA, it.rB, offA, offB);
+    Ops::read_frags(smem, 0, 0, wm, wn, lane, fa0, fb0);
     int cur = 0;
     for (int round = 0;; ++round) {
         const int Lnext = item_of(b, round + 1, G, total_items);
@@ -305,14 +339,24 @@ __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_bf16_kernel(Gem
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int k0 = it.kbeg; k0 < it.kend; k0 += BK) {
-            if (k0 + BK < it.kend)                      // in flight while this step is multiplied
-                Ops::stage(smem, cur ^ 1, (uint32_t)(k0 + BK) * kstrideA, (uint32_t)(k0 + BK) * kstrideB, w, it.rA, it.rB, offA, offB);
-            else if (Lnext >= 0)                        // first K step of the next item
-                Ops::stage(smem, cur ^ 1, (uint32_t)nxt.kbeg * kstrideA, (uint32_t)nxt.kbeg * kstrideB, w, nxt.rA, nxt.rB, offA, offB);
-            Ops::template multiply<NATURAL>(smem, cur, wm, wn, lane, acc);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                            // staged tile landed; everyone is done with buf[cur]
+        const int nsteps = (it.kend - it.kbeg + BK - 1) / BK;
+        for (int t = 0; t < nsteps; ++t) {
+            // phase A
+            Ops::read_frags(smem, cur, 1, wm, wn, lane, fa1, fb1);
+            Ops::template mfma_block<NATURAL>(fa0, fb0, acc);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            // tile t+2 -> buf[cur]
+            if (t + 2 < nsteps) {
+                const int k2 = it.kbeg + (t + 2) * BK;
+                Ops::stage(smem, cur, (uint32_t)k2 * kstrideA, (uint32_t)k2 * kstrideB, w, it.rA, it.rB, offA, offB);
+            } else if (Lnext >= 0) {
+                const int kn = nxt.kbeg + (t + 2 - nsteps) * BK;    // first or second tile of the next item
+                Ops::stage(smem, cur, (uint32_t)kn * kstrideA, (uint32_t)kn * kstrideB, w, nxt.rA, nxt.rB, offA, offB);
+            }
+            // phase B
+            if (t + 1 < nsteps || Lnext >= 0) Ops::read_frags(smem, cur ^ 1, 0, wm, wn, lane, fa0, fb0);
+            Ops::template mfma_block<NATURAL>(fa1, fb1, acc);
             cur ^= 1;
         }
         epilogue<Cfg, EPI>(p, it.m0, it.n0, wm, wn, lane, acc);
@@ -352,6 +396,10 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const int tiles_per_split = (ktiles + splits - 1) / splits;
     p.k_per_split = tiles_per_split * BK;
     splits = (ktiles + tiles_per_split - 1) / tiles_per_split;
+    if (Cfg::NBUF == 2 && (ktiles < 2 || (ktiles % tiles_per_split) == 1)) {
+        paced_set_error("internal: the double-buffered tile needs at least two K steps per work item");
+        return PACED_ERR_ARG;
+    }
     const int total = ntm * ntn * splits;
     const int grid = total < slots ? total : slots;
     constexpr int smem = Cfg::NBUF * (Cfg::BM + Cfg::BN) * BK * 2;
@@ -378,7 +426,24 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         large = p.M >= 256 && p.N >= 256 && (t256 >= 200 || (EPI == EPI_ATOMIC_F32 && t256 >= 24));
     }
-    if (large) return launch_cfg<CfgLarge, TA, TB, EPI>(p, splits, stream);
+    if (large && p.K >= 2 * BK) {
+        // every K slice must hold at least two K steps: settle the split here
+        const int ktiles = (p.K + BK - 1) / BK;
+        int sp = splits;
+        if (sp <= 0) {
+            const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+            const int slots = cu_count();
+            sp = (EPI == EPI_ATOMIC_F32 && tiles < slots) ? slots / tiles : 1;
+            if (sp > ktiles / 4) sp = ktiles / 4 > 0 ? ktiles / 4 : 1;
+        }
+        if (sp > ktiles / 2) sp = ktiles / 2;
+        while (sp > 1) {                                   // avoid a 1-step tail slice
+            const int per = (ktiles + sp - 1) / sp;
+            if (ktiles % per != 1) break;
+            --sp;
+        }
+        return launch_cfg<CfgLarge, TA, TB, EPI>(p, sp, stream);
+    }
     return launch_cfg<CfgSmall, TA, TB, EPI>(p, splits, stream);
 }
 
