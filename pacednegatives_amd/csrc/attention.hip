@@ -142,18 +142,22 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
+        const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * S;
+        const bool pair_ok = (dbase & 1) == 0;            // keys (r, r+1) with r even then share one hash
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __expf(s[j][r] - m_new);
-                psum += p;
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __expf(s[j][r] - m_new), p1 = __expf(s[j][r + 1] - m_new);
+                psum += p0 + p1;
+                float f0 = 1.f, f1 = 1.f;
                 if (a.drop.thresh) {
-                    const int key = kt * 64 + 32 * j + acc_row(r, hh);
-                    s[j][r] = p * drop_factor(a.drop, (((uint64_t)n * a.H + h) * S + qc) * S + key);
-                } else {
-                    s[j][r] = p;
+                    const int key = kt * 64 + 32 * j + acc_row(r, hh);      // even; register r+1 holds key+1
+                    if (pair_ok) drop_factor2(a.drop, dbase + key, f0, f1);
+                    else { f0 = drop_factor(a.drop, dbase + key); f1 = drop_factor(a.drop, dbase + key + 1); }
                 }
+                s[j][r] = p0 * f0;
+                s[j][r + 1] = p1 * f1;
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -387,13 +391,19 @@ __global__ void __launch_bounds__(256, 3) enc_attn_bwd_dq_kernel(AttnArgs a) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lKr, 32 * j, ks, lane), qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lVr, 32 * j, ks, lane), dof[ks], dp, 0, 0, 0);
             }
+            const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * S;
+            const bool pair_ok = (dbase & 1) == 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + 32 * j + acc_row(r, hh);
-                const float p = (key < S) ? __expf(s[r]) : 0.f;
-                float f = 1.f;
-                if (a.drop.thresh) f = drop_factor(a.drop, (((uint64_t)n * a.H + h) * S + qc) * S + min(key, S - 1));
-                s[r] = p * (dp[r] * f - delta);
+            for (int r = 0; r < 16; r += 2) {
+                const int key = kt * 64 + 32 * j + acc_row(r, hh);          // even; register r+1 holds key+1
+                const float p0 = (key < S) ? __expf(s[r]) : 0.f, p1 = (key + 1 < S) ? __expf(s[r + 1]) : 0.f;
+                float f0 = 1.f, f1 = 1.f;
+                if (a.drop.thresh) {
+                    if (pair_ok) drop_factor2(a.drop, dbase + key, f0, f1);
+                    else { f0 = drop_factor(a.drop, dbase + key); f1 = drop_factor(a.drop, dbase + key + 1); }
+                }
+                s[r] = p0 * (dp[r] * f0 - delta);
+                s[r + 1] = p1 * (dp[r + 1] * f1 - delta);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {

@@ -43,36 +43,46 @@ __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32: RNE, NaN kept
 
 // ---------------------------------------------------------------------------------------------
-// Counter-based dropout.  One 32-bit hash of (seed, 64-bit element index); an element is KEPT when
-// hash >= thresh where thresh = p * 2^32, and kept values are scaled by 1/(1-p).  Forward and
-// backward kernels recompute the same decision from the same (seed, index), so no mask is stored.
+// Counter-based dropout.  One 32-bit hash serves TWO neighbouring elements (indices 2i and 2i+1 take
+// its low and high 16 bits); an element is KEPT when its 16-bit value >= thresh16 = round(p * 65536),
+// so the realised rate is p quantised to 1/65536, and kept values are scaled by 1/(1 - thresh16/65536).
+// Forward and backward kernels recompute the same decision from the same (seed, index), so no mask
+// is ever stored.
 __host__ __device__ __forceinline__ uint32_t paced_mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__host__ __device__ __forceinline__ uint32_t paced_drop_hash(uint32_t seed, uint64_t idx) {
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t h = paced_mix32(lo ^ seed);
-    h = paced_mix32(h + 0x9e3779b9u * (hi + 1u) + (seed << 7) + (seed >> 3));
-    return h;
+__host__ __device__ __forceinline__ uint32_t paced_drop_bits(uint32_t seed, uint64_t idx) {
+    const uint32_t pair = (uint32_t)(idx >> 1), hi = (uint32_t)(idx >> 33);
+    const uint32_t h = paced_mix32((pair ^ seed) + hi * 0x9e3779b9u);
+    return (idx & 1) ? (h >> 16) : (h & 0xffffu);
 }
 struct DropCfg {
     uint32_t seed;
-    uint32_t thresh;   // 0 => dropout disabled
-    float scale;       // 1/(1-p)
+    uint32_t thresh;   // 16-bit threshold; 0 => dropout disabled
+    float scale;       // 1/(1-p) for the quantised p
 };
 __host__ __forceinline__ DropCfg make_drop(float p, uint32_t seed) {
     DropCfg d;
     d.seed = seed;
     if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; return d; }
-    double t = (double)p * 4294967296.0;
-    d.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
-    d.scale = 1.f / (1.f - p);
+    double t = (double)p * 65536.0 + 0.5;
+    d.thresh = t >= 65535.0 ? 65535u : (uint32_t)t;
+    if (d.thresh == 0) d.thresh = 1;
+    d.scale = (float)(1.0 / (1.0 - (double)d.thresh / 65536.0));
     return d;
 }
 __device__ __forceinline__ float drop_factor(const DropCfg& d, uint64_t idx) {
     if (d.thresh == 0) return 1.f;
-    return paced_drop_hash(d.seed, idx) >= d.thresh ? d.scale : 0.f;
+    return paced_drop_bits(d.seed, idx) >= d.thresh ? d.scale : 0.f;
+}
+// factors of the aligned pair (idx even, idx+1) from ONE hash
+__device__ __forceinline__ void drop_factor2(const DropCfg& d, uint64_t idx_even, float& f0, float& f1) {
+    if (d.thresh == 0) { f0 = 1.f; f1 = 1.f; return; }
+    const uint32_t pair = (uint32_t)(idx_even >> 1), hi = (uint32_t)(idx_even >> 33);
+    const uint32_t h = paced_mix32((pair ^ d.seed) + hi * 0x9e3779b9u);
+    f0 = (h & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    f1 = (h >> 16) >= d.thresh ? d.scale : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------

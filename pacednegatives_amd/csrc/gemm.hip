@@ -82,16 +82,26 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, int m, int n, co
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ci) = f32x4{v[0], v[1], v[2], v[3]};
         return;
     }
+    float f[4] = {1.f, 1.f, 1.f, 1.f};
+    if (EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP) {
+        if ((p.N & 1) == 0) {                       // di is even: one hash per two elements
+            drop_factor2(p.drop, di, f[0], f[1]);
+            drop_factor2(p.drop, di + 2, f[2], f[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[r] = drop_factor(p.drop, di + r);
+        }
+    }
     if (EPI == EPI_RES_DROP || EPI == EPI_MASK) {
         const bf16x4 x = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (EPI == EPI_RES_DROP) v[r] = bf2f(x[r]) + v[r] * drop_factor(p.drop, di + r);
+            if (EPI == EPI_RES_DROP) v[r] = bf2f(x[r]) + v[r] * f[r];
             else v[r] = bf2f(x[r]) > 0.f ? v[r] * p.mask_scale : 0.f;
         }
     } else if (EPI == EPI_RELU_DROP) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) * drop_factor(p.drop, di + r);
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) * f[r];
     }
     bf16x4 o;
 #pragma unroll
