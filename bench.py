@@ -89,12 +89,21 @@ def run_train(args, rank, world, device):
         ms = e0.elapsed_time(e1)
         s = by_sym.setdefault(key, [0.0, 0.0, 0])
         s[0] += flops; s[1] += ms * 1e-3; s[2] += 1
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")      # rocprofv3 --pmc passes of this same command
+    if os.path.exists(tpath) and (args.model, B, nneg, S) == ("t5-base", 32, 16, 256):
+        try:
+            traffic = json.load(open(tpath))["gemm_bf16_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     tot_f = sum(v[0] for v in by_sym.values())
     tot_t = sum(v[1] for v in by_sym.values())
     if tot_t > 0:
         dom = max(by_sym.items(), key=lambda kv: kv[1][1])
         roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": tot_f / tot_t / 1e12, "peak": BF16_DENSE_PEAK / 1e12,
-                "unit": "TFLOP/s", "frac": tot_f / tot_t / BF16_DENSE_PEAK, "traffic": None,
+                "unit": "TFLOP/s", "frac": tot_f / tot_t / BF16_DENSE_PEAK, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; profiles/r1_pmc_traffic.json)",
+                "flops_per_launch": tot_f / sum(v[2] for v in by_sym.values()),
                 "launches": sum(v[2] for v in by_sym.values()), "avg_launch_us": tot_t / sum(v[2] for v in by_sym.values()) * 1e6,
                 "slowest_variant": {"trans_a,trans_b,epilogue": dom[0], "TFLOP/s": dom[1][0] / dom[1][1] / 1e12,
                                     "launches": dom[1][2], "avg_launch_us": dom[1][1] / dom[1][2] * 1e6},
