@@ -100,7 +100,7 @@ def run_train(args, rank, world, device):
     tot_t = sum(v[1] for v in by_sym.values())
     if tot_t > 0:
         dom = max(by_sym.items(), key=lambda kv: kv[1][1])
-        roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": tot_f / tot_t / 1e12, "peak": BF16_DENSE_PEAK / 1e12,
+        roof = {"bound": "mfma", "kernel": "gemm_phased_kernel + gemm_bf16_kernel (all paced_gemm_bf16 launches)", "achieved": tot_f / tot_t / 1e12, "peak": BF16_DENSE_PEAK / 1e12,
                 "unit": "TFLOP/s", "frac": tot_f / tot_t / BF16_DENSE_PEAK, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; profiles/r1_pmc_traffic.json)",
                 "flops_per_launch": tot_f / sum(v[2] for v in by_sym.values()),

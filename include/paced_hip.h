@@ -55,7 +55,7 @@ int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
                     float drop_p, uint32_t drop_seed, int splits, void* stream);
 
 /* Tile selection of paced_gemm_bf16: 0 = heuristic (default), 128 = 128x128 tiles, 256 = 256x256
- * double-buffered tiles.  Process-wide; meant for benchmarking and tests. */
+ * phased tiles (one workgroup per CU, LDS ring).  Process-wide; meant for benchmarking and tests. */
 int paced_gemm_set_tile(int tile);
 
 /* ---- T5LayerNorm (RMS norm), HF:59-72; backward reached from lceT5.py:155 ------------------

@@ -6,28 +6,37 @@
 //   so (0,0) is y = x W^T (forward), (0,1) is dx = dy W (input gradient) and (1,1) is
 //   dW = dy^T x (weight gradient, contraction over tokens, split over workgroups, fp32 atomics).
 //
-// Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave, 4x4
-// v_mfma_f32_16x16x32_bf16 accumulators), K step 64.  Operand tiles go HBM -> LDS directly with
-// buffer_load_dwordx4 ... lds (16 B per lane, 1 KiB per wave instruction); the LDS image is
-// lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and again
-// on the fragment read.  K-contiguous tiles are read with ds_read_b128; K-strided tiles
+// Structure: persistent grid over (output tile, K slice) work items; K step 64.  Operand tiles go
+// HBM -> LDS directly with buffer_load_dwordx4 ... lds (16 B per lane, 1 KiB per wave instruction); the
+// LDS image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address and
+// again on the fragment read.  K-contiguous tiles are read with ds_read_b128; K-strided tiles
 // (transposed operands) are read with ds_read_b64_tr_b16.  Out-of-range rows rely on the buffer
 // descriptor's range check (loads beyond num_records return zero), so ragged M/N and a ragged
-// token contraction need no host-side padding.
+// token contraction need no host-side padding.  Two tile configurations: see below.
 #include "gemm.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int BK = 64;
 
-// Tile configurations: {BM, BN, waves along M, waves along N, LDS buffers}.
-//   small: 128x128, 4 waves, one LDS buffer, two barriers per K step; 3-4 workgroups per CU hide the
-//          staging latency.  Used for small outputs (decoder, 768-wide weight gradients).
-//   large: 256x256, 8 waves (2x4, 128x64 per wave), two LDS buffers (128 KiB): the LDS-DMA of K step
-//          t+1 is in flight while step t is multiplied; one barrier per K step; one workgroup per CU.
+// Tile configurations.
+//   small:  128x128 output tile, 4 waves (2x2, 64x64 per wave), one LDS buffer, two barriers per K step;
+//           three workgroups per CU hide the staging latency.  Small outputs (decoder, ragged shapes).
+//   phased: 256x256 output tile, 8 waves (2x4), one workgroup per CU, all 160 KiB of LDS as a ring of
+//           half-tiles; see the kernel below.  moff/noff give the tile-relative origin of a wave's
+//           i-th / j-th 16x16 accumulator block.
 }  // namespace
-struct CfgSmall { static constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2, NBUF = 1; };
-struct CfgLarge { static constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4, NBUF = 2; };
+struct CfgSmall {
+    static constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2, MI = 4, NJ = 4;
+    static __device__ __forceinline__ int moff(int wm, int i) { return wm * 64 + i * 16; }
+    static __device__ __forceinline__ int noff(int wn, int j) { return wn * 64 + j * 16; }
+};
+struct CfgPhased {
+    static constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4, MI = 8, NJ = 4;
+    static __device__ __forceinline__ int moff(int wm, int i) { return (i >> 2) * 128 + wm * 64 + (i & 3) * 16; }
+    static __device__ __forceinline__ int noff(int wn, int j) { return wn * 64 + j * 16; }   // B halves interleave 32-column blocks
+};
 namespace {
 
 // Per-lane source offset (bytes, relative to the tile's first row / column) of the 16-byte chunk
@@ -35,23 +44,31 @@ namespace {
 //   K-contiguous operand : image [ROWS][64] bf16, 128-byte rows; chunk c of row r sits at c ^ ((r>>1)&7).
 //   K-strided operand    : image [64][ROWS] bf16; the 32-byte unit u of k-row k sits at u ^ h(k),
 //                          h(k) = (k&3) | ((k>>3)&1)<<2  (conflict-free ds_read_b64_tr_b16).
-template <bool TRANS, int ROWS>
+// With SPLIT (the phased kernel's B halves) image row r of a half is tile row (r>>5)*64 + (r&31): a
+// half holds one 32-row block out of every 64 rows, so that a wave's two 32-row slices (one per half)
+// are 64 CONSECUTIVE tile rows.
+template <bool TRANS, int ROWS, bool SPLIT = false>
 __device__ __forceinline__ uint32_t stage_offset(int g, int ld) {
     if (!TRANS) {
         const int r = g >> 3, cs = g & 7;
         const int c = cs ^ ((r >> 1) & 7);
-        return (uint32_t)(r * ld + c * 8) * 2u;
+        const int rs = SPLIT ? ((r >> 5) * 64 + (r & 31)) : r;
+        return (uint32_t)(rs * ld + c * 8) * 2u;
     } else {
         constexpr int CPR = ROWS / 8;                 // 16-byte chunks per k-row
         const int k = g / CPR, cs = g % CPR;
         const int hk = (k & 3) | (((k >> 3) & 1) << 2);
         const int c = (((cs >> 1) ^ hk) << 1) | (cs & 1);
-        return (uint32_t)(k * ld + c * 8) * 2u;
+        const int csrc = SPLIT ? ((c >> 2) * 8 + (c & 3)) : c;
+        return (uint32_t)(k * ld + csrc * 8) * 2u;
     }
 }
 
 // 16 rows x 32 k fragment (one v_mfma_f32_16x16x32_bf16 operand) for rows rb..rb+15, k-step kk.
-template <bool TRANS, int ROWS>
+// With RAW_ASM the transposed reads are issued as inline assembly: the compiler then neither waits
+// for them (the caller must s_waitcnt lgkmcnt before the first use) nor drains every LDS-DMA in flight
+// ahead of them, which it does for the builtin (it cannot tell that the DMA targets another slot).
+template <bool TRANS, int ROWS, bool RAW_ASM = false>
 __device__ __forceinline__ bf16x8 read_frag(const char* tile, int rb, int kk, int lane) {
     if (!TRANS) {
         const int row = rb + (lane & 15);
@@ -65,8 +82,15 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int rb, int kk, in
         const int hk = q | ((g & 1) << 2);
         const int k0 = kk * 32 + 8 * g + q;
         const int addr0 = k0 * RB + ((u ^ hk) << 5) + p * 8;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + addr0));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + addr0 + 4 * RB));
+        bf16x4 lo, hi;
+        if (RAW_ASM) {
+            const uint32_t a = (uint32_t)(uintptr_t)LDS_PTR(tile + addr0);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(4 * RB));
+        } else {
+            lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + addr0));
+            hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(tile + addr0 + 4 * RB));
+        }
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
@@ -128,29 +152,6 @@ struct TileOps {
 #pragma unroll
         for (int i = 0; i < IB; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_PTR(lB + (i * NW + w) * 1024), 16, offB[i], sB, 0, 0);
-    }
-
-    // fragments of half a K step (k = 32*kk .. +32) from LDS buffer `buf`
-    static __device__ __forceinline__ void read_frags(const char* smem, int buf, int kk, int wm, int wn, int lane,
-                                                      bf16x8 (&fa)[MI], bf16x8 (&fb)[NJ]) {
-        const char* lA = smem + buf * BUF_BYTES;
-        const char* lB = lA + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[j] = read_frag<TB, BN>(lB, wn * TN + j * 16, kk, lane);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = read_frag<TA, BM>(lA, wm * TM + i * 16, kk, lane);
-    }
-    template <bool NATURAL>
-    static __device__ __forceinline__ void mfma_block(const bf16x8 (&fa)[MI], const bf16x8 (&fb)[NJ], f32x4 (&acc)[MI][NJ]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (NATURAL) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            }
-        __builtin_amdgcn_s_setprio(0);
     }
 
     // multiply the K step held in LDS buffer `buf` into the accumulators
@@ -224,12 +225,12 @@ __device__ __forceinline__ int item_of(int b, int round, int G, int T) {
 
 template <class Cfg, int EPI>
 __device__ __forceinline__ void epilogue(const GemmParams& p, int m0, int n0, int wm, int wn, int lane,
-                                         f32x4 (&acc)[Cfg::BM / Cfg::WGM / 16][Cfg::BN / Cfg::WGN / 16]) {
-    constexpr int TM = Cfg::BM / Cfg::WGM, TN = Cfg::BN / Cfg::WGN, MI = TM / 16, NJ = TN / 16;
+                                         f32x4 (&acc)[Cfg::MI][Cfg::NJ]) {
+    constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
     if (EPI == EPI_TOPK_DENSE || EPI == EPI_TOPK_FILTER) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wn * TN + j * 16 + (lane & 15);
+            const int n = n0 + Cfg::noff(wn, j) + (lane & 15);
             if (n >= p.N) continue;
             const float thr = (EPI == EPI_TOPK_FILTER) ? p.tk_thr[n] : 0.f;
             unsigned long long* cand = p.tk_cand + (size_t)n * p.tk_cap;
@@ -237,7 +238,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m0, int n0, in
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
+                    const int m = m0 + Cfg::moff(wm, i) + (lane >> 4) * 4 + r;
                     if (m >= p.M) continue;
                     const float sc = acc[i][j][r];
                     if (EPI == EPI_TOPK_DENSE) {
@@ -256,10 +257,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m0, int n0, in
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * TN + j * 16 + (lane & 15);
+                const int n = n0 + Cfg::noff(wn, j) + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
+                    const int m = m0 + Cfg::moff(wm, i) + (lane >> 4) * 4 + r;
                     if (m < p.M && n < p.N) atomicAdd(C + (size_t)m * p.ldc + n, acc[i][j][r] * p.alpha);
                 }
             }
@@ -267,20 +268,18 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m0, int n0, in
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * TM + i * 16 + (lane & 15);
+        const int m = m0 + Cfg::moff(wm, i) + (lane & 15);
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
+            const int n = n0 + Cfg::noff(wn, j) + (lane >> 4) * 4;
             if (n >= p.N) continue;          // N is a multiple of 4 (checked on the host)
             store_quad<EPI>(p, m, n, acc[i][j]);
         }
     }
 }
 
-// Persistent kernel: gridDim.x workgroups walk `total_items` work items round by round.  With two
-// LDS buffers the first K step of the NEXT item is staged during the last K step of the current
-// one, so the epilogue's stores overlap the next item's loads and no pipeline refill is exposed.
+// Small-tile persistent kernel: gridDim.x workgroups walk `total_items` work items round by round.
 template <class Cfg, bool TA, bool TB, int EPI>
 __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_bf16_kernel(GemmParams p, int ntm, int ntn, int total_items) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NW = Cfg::WGM * Cfg::WGN;
@@ -306,7 +305,7 @@ __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_bf16_kernel(Gem
     WorkItem it = decode_item<Cfg, TA, TB>(p, L, ntm, ntn);
     f32x4 acc[MI][NJ];
 
-    if (Cfg::NBUF == 1) {
+    {
         for (int round = 0; L >= 0; ) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -323,56 +322,332 @@ __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_bf16_kernel(Gem
             L = item_of(b, ++round, G, total_items);
             if (L >= 0) it = decode_item<Cfg, TA, TB>(p, L, ntm, ntn);
         }
-        return;
     }
+}
 
-    // ---- two LDS buffers, two fragment register sets, one barrier per K step placed MID-step:
-    //   phase A: MFMA(set0 = first half of tile t)  ||  ds_read set1 = second half of tile t
-    //   wait own LDS reads + own LDS-DMA, barrier     -> tile t+1 has landed, nobody reads buf[cur] any more
-    //   issue LDS-DMA of tile t+2 into buf[cur]
-    //   phase B: MFMA(set1)  ||  ds_read set0 = first half of tile t+1 (from buf[cur^1])
-    // so fragment reads and the DMA always run under MFMAs.  "tile t+1 / t+2" continue into the next
-    // work item (every item has at least two K steps: checked on the host), whose first tiles are
-    // therefore already in flight while this item's epilogue stores drain.
-    bf16x8 fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
-    Ops::stage(smem, 0, (uint32_t)it.kbeg * kstrideA, (uint32_t)it.kbeg * kstrideB, w, it.rA, it.rB, offA, offB);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    Ops::stage(smem, 1, (uint32_t)(it.kbeg + BK) * kstrideA, (uint32_t)(it.kbeg + BK) * kstrideB, w, it.rA, it.rB, offA, offB);
-    Ops::read_frags(smem, 0, 0, wm, wn, lane, fa0, fb0);
-    int cur = 0;
-    for (int round = 0;; ++round) {
-        const int Lnext = item_of(b, round + 1, G, total_items);
-        WorkItem nxt = it;
-        if (Lnext >= 0) nxt = decode_item<Cfg, TA, TB>(p, Lnext, ntm, ntn);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nsteps = (it.kend - it.kbeg + BK - 1) / BK;
-        for (int t = 0; t < nsteps; ++t) {
-            // phase A
-            Ops::read_frags(smem, cur, 1, wm, wn, lane, fa1, fb1);
-            Ops::template mfma_block<NATURAL>(fa0, fb0, acc);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();
-            // tile t+2 -> buf[cur]
-            if (t + 2 < nsteps) {
-                const int k2 = it.kbeg + (t + 2) * BK;
-                Ops::stage(smem, cur, (uint32_t)k2 * kstrideA, (uint32_t)k2 * kstrideB, w, it.rA, it.rB, offA, offB);
-            } else if (Lnext >= 0) {
-                const int kn = nxt.kbeg + (t + 2 - nsteps) * BK;    // first or second tile of the next item
-                Ops::stage(smem, cur, (uint32_t)kn * kstrideA, (uint32_t)kn * kstrideB, w, nxt.rA, nxt.rB, offA, offB);
+// ---------------------------------------------------------------------------------------------
+// Phased 256x256 kernel.
+//
+// LDS: a ring of ten 16 KiB half-tile slots (all 160 KiB).  The operand stream is the sequence of
+// half-tiles  B half 0, A half 0, B half 1, A half 1  of K step 0, then of K step 1, ...; stream item s
+// lives in slot s mod 10, and a half is the 128-row tile image of the small configuration (same
+// source swizzle, same fragment reads).  K step T runs as four phases g = 4T .. 4T+3; every phase is
+//     ds_read the fragments it needs | issue the LDS-DMA of stream item g+8 | s_waitcnt vmcnt(12) |
+//     s_barrier | 16 MFMAs (one 64x32 quadrant x 64 deep) | s_barrier
+// (A half h is tile rows 128h..128h+127 and a wave owns 64 of them; B half h is the h-th 32-column
+// block of every 64 columns and a wave owns one such block per half, i.e. 64 consecutive columns.)
+//   phase 1: read B half 0 (4) and A half 0 (8);  quadrant (0,0)
+//   phase 2: read B half 1 (4);                   quadrant (0,1)
+//   phase 3: read A half 1 (8);                   quadrant (1,1)
+//   phase 4: nothing to read;                     quadrant (1,0)
+// so six half-tiles (96 KiB per workgroup) stay in flight across the raw barriers and a half-tile has
+// six phases (1.5 K steps) to land.  Ordering rules this relies on (LDS-DMA data is ordered for a
+// ds_read only by the issuing wave's vmcnt wait followed by a barrier the reader has passed; the two
+// wave groups run one barrier apart):
+//   * item s is read in phase s-1 at the earliest; the wait of phase g retires items <= g+2, so an
+//     item is read no earlier than the phase AFTER the wait that retires it;
+//   * item s is issued in phase s-8 into the slot of item s-10, whose last read was in phase s-10 at
+//     the latest: a slot is overwritten at least two phases after its last read.
+// The stream runs across work items (persistent grid), so the next item's first K steps are in flight
+// during an item's last phases and its epilogue.  Past the last item the stream issues the same DMAs
+// through a zero-length descriptor (they write zeros nobody reads): the vmcnt arithmetic stays
+// uniform and needs no tail case.
+struct TileSrc {
+    __amdgpu_buffer_rsrc_t rA, rB;
+    uint32_t sA, sB;       // scalar byte offsets of the K step inside the descriptors
+};
+
+template <bool TA, bool TB>
+struct StepStream {
+    WorkItem wi;
+    int k, round;
+    bool live;
+    __device__ __forceinline__ TileSrc take(const GemmParams& p, int b, int G, int ntm, int ntn, int total_items,
+                                            uint32_t kstrideA, uint32_t kstrideB) {
+        TileSrc ts;
+        if (live) {
+            ts.rA = wi.rA; ts.rB = wi.rB;
+            ts.sA = (uint32_t)k * kstrideA; ts.sB = (uint32_t)k * kstrideB;
+            k += BK;
+            if (k >= wi.kend) {
+                const int Ln = item_of(b, ++round, G, total_items);
+                if (Ln >= 0) { wi = decode_item<CfgPhased, TA, TB>(p, Ln, ntm, ntn); k = wi.kbeg; }
+                else live = false;
             }
-            // phase B
-            if (t + 1 < nsteps || Lnext >= 0) Ops::read_frags(smem, cur ^ 1, 0, wm, wn, lane, fa0, fb0);
-            Ops::template mfma_block<NATURAL>(fa1, fb1, acc);
-            cur ^= 1;
+        } else {
+            ts.rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+            ts.rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0, 0x00020000);
+            ts.sA = 0; ts.sB = 0;
         }
-        epilogue<Cfg, EPI>(p, it.m0, it.n0, wm, wn, lane, acc);
-        if (Lnext < 0) break;
-        it = nxt;
+        return ts;
     }
+};
+
+#define PACED_STAGE_HALF(rsrc, dst, off, soff)                                                           \
+    do {                                                                                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), LDS_PTR((dst)), 16, (off)[0], (soff), 0, 0);         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), LDS_PTR((dst) + 8192), 16, (off)[1], (soff), 0, 0);  \
+    } while (0)
+
+// Empty volatile asm that "rewrites" the eight accumulators of a quadrant: MFMAs are pure register
+// operations, which instruction selection otherwise floats across the barriers into the load sections.
+__device__ __forceinline__ void pin_quadrant(f32x4 (&acc)[8][4], int ha, int hb) {
+    asm volatile("" : "+v"(acc[ha * 4 + 0][hb * 2 + 0]), "+v"(acc[ha * 4 + 0][hb * 2 + 1]),
+                      "+v"(acc[ha * 4 + 1][hb * 2 + 0]), "+v"(acc[ha * 4 + 1][hb * 2 + 1]),
+                      "+v"(acc[ha * 4 + 2][hb * 2 + 0]), "+v"(acc[ha * 4 + 2][hb * 2 + 1]),
+                      "+v"(acc[ha * 4 + 3][hb * 2 + 0]), "+v"(acc[ha * 4 + 3][hb * 2 + 1]));
+}
+
+template <bool NATURAL>
+__device__ __forceinline__ void quadrant_mfma(const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2], f32x4 (&acc)[8][4], int ha, int hb) {
+    pin_quadrant(acc, ha, hb);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4& c = acc[ha * 4 + i][hb * 2 + j];
+                if (NATURAL) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], fb[j][kk], c, 0, 0, 0);
+                else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], c, 0, 0, 0);
+            }
+    __builtin_amdgcn_s_setprio(0);
+    pin_quadrant(acc, ha, hb);
+}
+
+// Transposed fragment reads are inline assembly here (see read_frag): wait for all LDS reads of the
+// phase before its MFMAs, and keep the scheduler from hoisting anything above the wait.
+#define PACED_WAIT_LDS_READS()                                \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                    \
+    } while (0)
+
+// a raw barrier that the instruction scheduler may not move anything across (MFMAs included)
+#define PACED_PINNED_BARRIER()                 \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+__device__ __forceinline__ int ring_wrap(int x) { return x >= 10 ? x - 10 : x; }
+
+// Epilogue of the phased kernel for bf16 outputs.  The MFMA layout gives a lane 4 consecutive columns
+// of one row (8-byte stores, 32-byte runs per row); instead every 16-row block of the wave's 128 x 64
+// result goes through 2 KiB of LDS as bf16 and comes back with 8 lanes covering a whole 128-byte row,
+// so residual/mask loads and the stores move full lines, 16 bytes per lane.  The staging LDS is the
+// wave's own 1 KiB pieces of the two ring slots that are dead at this point (the pieces the wave
+// itself overwrites with its next two LDS-DMAs), so no barrier is involved.  Values are rounded to
+// bf16 before the transposition: C = bf16(aux + bf16(dropout(acc))) for the residual form.
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, int m0, int n0, int wr, int wc, int lane,
+                                              f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
+    const int rr = lane >> 3, c = lane & 7;
+    const int ncol = n0 + wc * 64 + c * 8;
+    const bool col_ok = ncol < p.N;                   // N is a multiple of 8 on this path
+    bf16x8 aux[8][2];
+    if (EPI == EPI_RES_DROP || EPI == EPI_MASK) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
+                aux[i][q] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < p.M && col_ok) aux[i][q] = *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + ncol);
+            }
+    }
+    const int mw = lane & 15, g = lane >> 4;
+    const int wsw = ((mw & 7) << 1) | (mw >> 3);
+    const int woff = (mw & 7) * 128;
+    const int roff = rr * 128 + ((c ^ rr) << 4);
+    const bool has_drop = (EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP) && p.drop.thresh != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        char* pa = (i & 1) ? pc2 : pc0;
+        char* pb = (i & 1) ? pc3 : pc1;
+        char* pw = (mw < 8 ? pa : pb) + woff;
+        const uint64_t drow = (uint64_t)(m0 + CfgPhased::moff(wr, i) + mw) * (uint64_t)p.N + (uint64_t)(n0 + wc * 64 + g * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+            if (EPI == EPI_RELU_DROP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (EPI == EPI_MASK) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= p.mask_scale;
+            }
+            if (has_drop) {
+                float f[4];
+                drop_factor2(p.drop, drow + j * 16, f[0], f[1]);
+                drop_factor2(p.drop, drow + j * 16 + 2, f[2], f[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= f[r];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+            *reinterpret_cast<bf16x4*>(pw + (((j * 4 + g) ^ wsw) << 3)) = o;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16x8 t = *reinterpret_cast<const bf16x8*>((q ? pb : pa) + roff);
+            if (q) t = __builtin_shufflevector(t, t, 4, 5, 6, 7, 0, 1, 2, 3);      // rows 8..15 were stored with their 8-byte halves swapped
+            if (EPI == EPI_RES_DROP) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = f2bf(bf2f(aux[i][q][e]) + bf2f(t[e]));
+            } else if (EPI == EPI_MASK) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = bf2f(aux[i][q][e]) > 0.f ? t[e] : (bf16)0.f;
+            }
+            const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
+            if (m < p.M && col_ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + ncol) = t;
+        }
+    }
+}
+
+template <bool TA, bool TB, int EPI>
+__global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm, int ntn, int total_items) {
+    constexpr bool NATURAL = (EPI == EPI_ATOMIC_F32 || EPI == EPI_TOPK_DENSE || EPI == EPI_TOPK_FILTER);
+    constexpr int HALF = 16384;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int G = gridDim.x, b = blockIdx.x;
+
+    uint32_t offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offA[i] = stage_offset<TA, 128>((i * 8 + w) * 64 + lane, p.lda);
+        offB[i] = stage_offset<TB, 128, true>((i * 8 + w) * 64 + lane, p.ldb);
+    }
+    const uint32_t kstrideA = TA ? (uint32_t)p.lda * 2u : 2u;
+    const uint32_t kstrideB = TB ? (uint32_t)p.ldb * 2u : 2u;
+    const uint32_t halfA = TA ? 256u : 256u * (uint32_t)p.lda;      // bytes from half 0 to half 1 (128 rows)
+    const uint32_t halfB = TB ? 64u : 64u * (uint32_t)p.ldb;          // B half 1 starts 32 rows after half 0
+    char* const sw = smem + w * 1024;                                // this wave's slice of a half-tile image
+
+    int L = item_of(b, 0, G, total_items);
+    if (L < 0) return;
+    StepStream<TA, TB> st;
+    st.wi = decode_item<CfgPhased, TA, TB>(p, L, ntm, ntn);
+    st.k = st.wi.kbeg; st.round = 0; st.live = true;
+    int m0 = st.wi.m0, n0 = st.wi.n0;
+    int nsteps = (st.wi.kend - st.wi.kbeg + BK - 1) / BK;
+
+    {
+        const TileSrc c0 = st.take(p, b, G, ntm, ntn, total_items, kstrideA, kstrideB);
+        const TileSrc c1 = st.take(p, b, G, ntm, ntn, total_items, kstrideA, kstrideB);
+        PACED_STAGE_HALF(c0.rB, sw + 0 * HALF, offB, c0.sB);
+        PACED_STAGE_HALF(c0.rA, sw + 1 * HALF, offA, c0.sA);
+        PACED_STAGE_HALF(c0.rB, sw + 2 * HALF, offB, c0.sB + halfB);
+        PACED_STAGE_HALF(c0.rA, sw + 3 * HALF, offA, c0.sA + halfA);
+        PACED_STAGE_HALF(c1.rB, sw + 4 * HALF, offB, c1.sB);
+        PACED_STAGE_HALF(c1.rA, sw + 5 * HALF, offA, c1.sA);
+        PACED_STAGE_HALF(c1.rB, sw + 6 * HALF, offB, c1.sB + halfB);
+        PACED_STAGE_HALF(c1.rA, sw + 7 * HALF, offA, c1.sA + halfA);
+    }
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // second wave group runs one barrier behind
+    TileSrc c2 = st.take(p, b, G, ntm, ntn, total_items, kstrideA, kstrideB);
+
+    f32x4 acc[8][4];
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    int base = 0;                                     // ring slot of this K step's first half-tile
+    for (int round = 0;;) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nsteps; ++t) {
+            const int sB0 = base, sA0 = ring_wrap(base + 1), sB1 = ring_wrap(base + 2), sA1 = ring_wrap(base + 3);
+            const int d1 = ring_wrap(base + 8), d2 = ring_wrap(base + 9);      // phases 3 and 4 reuse sB0 and sA0
+            // ---- phase 1
+            {
+                const char* lB = smem + sB0 * HALF;
+                const char* lA = smem + sA0 * HALF;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) fb0[j][kk] = read_frag<TB, 128, true>(lB, wc * 32 + j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag<TA, 128, true>(lA, wr * 64 + i * 16, kk, lane);
+            }
+            PACED_STAGE_HALF(c2.rB, sw + d1 * HALF, offB, c2.sB);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            PACED_PINNED_BARRIER();
+            PACED_WAIT_LDS_READS();
+            quadrant_mfma<NATURAL>(fa, fb0, acc, 0, 0);
+            PACED_PINNED_BARRIER();
+            // ---- phase 2
+            {
+                const char* lB = smem + sB1 * HALF;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) fb1[j][kk] = read_frag<TB, 128, true>(lB, wc * 32 + j * 16, kk, lane);
+            }
+            PACED_STAGE_HALF(c2.rA, sw + d2 * HALF, offA, c2.sA);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            PACED_PINNED_BARRIER();
+            PACED_WAIT_LDS_READS();
+            quadrant_mfma<NATURAL>(fa, fb1, acc, 0, 1);
+            PACED_PINNED_BARRIER();
+            // ---- phase 3
+            {
+                const char* lA = smem + sA1 * HALF;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) fa[i][kk] = read_frag<TA, 128, true>(lA, wr * 64 + i * 16, kk, lane);
+            }
+            PACED_STAGE_HALF(c2.rB, sw + sB0 * HALF, offB, c2.sB + halfB);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            PACED_PINNED_BARRIER();
+            PACED_WAIT_LDS_READS();
+            quadrant_mfma<NATURAL>(fa, fb1, acc, 1, 1);
+            PACED_PINNED_BARRIER();
+            // ---- phase 4
+            PACED_STAGE_HALF(c2.rA, sw + sA0 * HALF, offA, c2.sA + halfA);
+            // the scalar bookkeeping of the next K step runs here, under the partner group's MFMAs
+            c2 = st.take(p, b, G, ntm, ntn, total_items, kstrideA, kstrideB);
+            base = ring_wrap(base + 4);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            PACED_PINNED_BARRIER();
+            quadrant_mfma<NATURAL>(fa, fb0, acc, 1, 0);
+            PACED_PINNED_BARRIER();
+        }
+        if (EPI == EPI_BF16 || EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP || EPI == EPI_MASK) {
+            char* s1 = sw + ring_wrap(base + 8) * HALF;      // the finished K step's B half 1 and A half 1 slots
+            char* s2 = sw + ring_wrap(base + 9) * HALF;
+            epilogue_rows<EPI>(p, m0, n0, wr, wc, lane, acc, s1, s1 + 8192, s2, s2 + 8192);
+        } else {
+            epilogue<CfgPhased, EPI>(p, m0, n0, wr, wc, lane, acc);
+        }
+        L = item_of(b, ++round, G, total_items);
+        if (L < 0) break;
+        {
+            // position and K-step count of the next item (the stream decoded it already for its loads)
+            const int ntiles = ntm * ntn;
+            const int split = L / ntiles, tt = L - split * ntiles;
+            int tm, tn;
+            if (ntm >= ntn) { tm = tt / ntn; tn = tt - tm * ntn; } else { tn = tt / ntm; tm = tt - tn * ntm; }
+            m0 = tm * 256; n0 = tn * 256;
+            const int kb = split * p.k_per_split, ke = min(p.K, kb + p.k_per_split);
+            nsteps = (ke - kb + BK - 1) / BK;
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 namespace {
@@ -395,8 +670,8 @@ template <class Cfg, bool TA, bool TB, int EPI>
 int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const int ntm = (p.M + Cfg::BM - 1) / Cfg::BM, ntn = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int ktiles = (p.K + BK - 1) / BK;
-    const int wg_per_cu = Cfg::NBUF == 2 ? 1 : 3;
-    const int slots = cu_count() * wg_per_cu;
+    constexpr bool PHASED = std::is_same<Cfg, CfgPhased>::value;
+    const int slots = cu_count() * (PHASED ? 1 : 3);     // workgroups resident per CU
     if (splits <= 0) {          // auto: fill the persistent grid once, keep >= 4 K steps per slice
         splits = 1;
         if (EPI == EPI_ATOMIC_F32 && ntm * ntn < slots) splits = slots / (ntm * ntn);
@@ -406,22 +681,21 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const int tiles_per_split = (ktiles + splits - 1) / splits;
     p.k_per_split = tiles_per_split * BK;
     splits = (ktiles + tiles_per_split - 1) / tiles_per_split;
-    if (Cfg::NBUF == 2 && (ktiles < 2 || (ktiles % tiles_per_split) == 1)) {
-        paced_set_error("internal: the double-buffered tile needs at least two K steps per work item");
-        return PACED_ERR_ARG;
-    }
     const int total = ntm * ntn * splits;
     const int grid = total < slots ? total : slots;
-    constexpr int smem = Cfg::NBUF * (Cfg::BM + Cfg::BN) * BK * 2;
+    constexpr int smem = PHASED ? 163840 : (Cfg::BM + Cfg::BN) * BK * 2;
     if (smem > 65536) {
         static bool attr_set = false;     // one flag per template instantiation
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<Cfg, TA, TB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipError_t e;
+            if constexpr (PHASED) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_phased_kernel<TA, TB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<Cfg, TA, TB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) { paced_set_error("hipFuncSetAttribute(%d bytes LDS) failed: %s", smem, hipGetErrorString(e)); return PACED_ERR_HIP; }
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<Cfg, TA, TB, EPI>), dim3(grid), dim3(Cfg::WGM * Cfg::WGN * 64), smem, stream, p, ntm, ntn, total);
+    if constexpr (PHASED) hipLaunchKernelGGL((gemm_phased_kernel<TA, TB, EPI>), dim3(grid), dim3(512), smem, stream, p, ntm, ntn, total);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<Cfg, TA, TB, EPI>), dim3(grid), dim3(Cfg::WGM * Cfg::WGN * 64), smem, stream, p, ntm, ntn, total);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }
@@ -432,28 +706,15 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
     if (g_force_tile == 128) large = false;
     else if (g_force_tile == 256) large = true;
     else {
-        // the large tile pays off once there is about one tile per CU (split slices count for atomics)
+        // the 256x256 tile pays off once there is about one tile per CU (split slices count for atomics)
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        large = p.M >= 256 && p.N >= 256 && (t256 >= 200 || (EPI == EPI_ATOMIC_F32 && t256 >= 24));
+        large = p.M >= 256 && p.N >= 256 && (t256 >= 200 || (EPI == EPI_ATOMIC_F32 && t256 >= 9));
     }
-    if (large && p.K >= 2 * BK) {
-        // every K slice must hold at least two K steps: settle the split here
-        const int ktiles = (p.K + BK - 1) / BK;
-        int sp = splits;
-        if (sp <= 0) {
-            const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-            const int slots = cu_count();
-            sp = (EPI == EPI_ATOMIC_F32 && tiles < slots) ? slots / tiles : 1;
-            if (sp > ktiles / 4) sp = ktiles / 4 > 0 ? ktiles / 4 : 1;
-        }
-        if (sp > ktiles / 2) sp = ktiles / 2;
-        while (sp > 1) {                                   // avoid a 1-step tail slice
-            const int per = (ktiles + sp - 1) / sp;
-            if (ktiles % per != 1) break;
-            --sp;
-        }
-        return launch_cfg<CfgLarge, TA, TB, EPI>(p, sp, stream);
-    }
+    // the phased kernel moves bf16 outputs (and their residual / mask operand) in 16-byte row pieces
+    const bool rows16 = (EPI == EPI_F32 || EPI == EPI_ATOMIC_F32 || EPI == EPI_TOPK_DENSE || EPI == EPI_TOPK_FILTER) ||
+                        (p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
+                         (!(EPI == EPI_RES_DROP || EPI == EPI_MASK) || (p.ldaux % 8 == 0 && ((uintptr_t)p.aux & 15) == 0)));
+    if (large && rows16) return launch_cfg<CfgPhased, TA, TB, EPI>(p, splits, stream);
     return launch_cfg<CfgSmall, TA, TB, EPI>(p, splits, stream);
 }
 

@@ -58,6 +58,29 @@ def test_gemm_exact_integers(M, N, K_, ta, tb, tile):
     assert torch.equal(c.cpu(), want)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_many_tiles_per_workgroup_exact(ta, tb, tile):
+    """More output tiles than compute units: every persistent workgroup walks several work items, the
+    last ones ragged in both directions."""
+    M, N, Kc = 5000, 4104, 192
+    if ta:
+        Kc += 40
+    a = ints((M, Kc), -2, 2, 21)
+    b = ints((N, Kc), -2, 2, 22)
+    A = bf(a.t() if ta else a)
+    B = bf(b.t() if tb else b)
+    want = A.float().t() @ B.float() if (ta and tb) else (A.float() @ (B.float() if tb else B.float().t()))
+    c = torch.full((M, N), float("nan"), device=DEV)
+    K.gemm(A, B, c, trans_a=ta, trans_b=tb, epilogue=K.EPI_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(c, want)
+    if ta:
+        c2 = torch.zeros(M, N, device=DEV)
+        K.gemm(A, B, c2, trans_a=ta, trans_b=tb, epilogue=K.EPI_ATOMIC_F32, splits=2)
+        torch.cuda.synchronize()
+        assert torch.equal(c2, want)
+
+
 def test_gemm_strided_views_and_alpha(tile):
     a = ints((200, 128), -2, 2, 3)
     b = ints((72, 128), -2, 2, 4)
@@ -79,11 +102,14 @@ def test_gemm_epilogues(tile):
     out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
     K.gemm(A, B, out, epilogue=K.EPI_BF16)
     assert torch.equal(out.float().cpu(), acc.to(torch.bfloat16).float())
+    # residual form: a tile configuration may round the product to bf16 before the add (what a bf16 linear
+    # layer followed by a bf16 add does) or add in fp32; both are within one bf16 ulp of the exact sum
+    want = acc + res
     K.gemm(A, B, out, epilogue=K.EPI_RES_DROP, aux=R)
-    assert torch.equal(out.float().cpu(), (acc + res).to(torch.bfloat16).float())
+    assert ((out.float().cpu() - want).abs() <= want.abs() * 2 ** -7).all()
     inplace = R.clone()
     K.gemm(A, B, inplace, epilogue=K.EPI_RES_DROP, aux=inplace)
-    assert torch.equal(inplace.float().cpu(), (acc + res).to(torch.bfloat16).float())
+    assert torch.equal(inplace, out)
     K.gemm(A, B, out, epilogue=K.EPI_RELU_DROP)
     assert torch.equal(out.float().cpu(), acc.clamp_min(0).to(torch.bfloat16).float())
     K.gemm(A, B, out, epilogue=K.EPI_MASK, aux=R, mask_scale=2.0)
@@ -126,8 +152,9 @@ def test_gemm_dropout_matches_mask_function(tile):
     res = bf(ints((M, N), -9, 9, 14))
     K.gemm(bf(a), bf(b), out, epilogue=K.EPI_RES_DROP, aux=res, drop_p=p, drop_seed=seed)
     # the kernel may contract res + acc*factor into one fma (one rounding instead of two): allow 1 bf16 ulp
+    # (or round acc*factor to bf16 first and then add: one more half-ulp of that product)
     want = res.float() + acc * mask
-    assert ((out.float() - want).abs() <= want.abs() * 2 ** -7 + 1e-6).all()
+    assert ((out.float() - want).abs() <= want.abs() * 2 ** -7 + (acc * mask).abs() * 2 ** -8 + 1e-6).all()
     assert torch.equal((out.float() == res.float()), (mask == 0) | (acc == 0))
     y = torch.empty(M * N, device=DEV, dtype=torch.bfloat16)
     x = bf(acc.cpu().reshape(-1))

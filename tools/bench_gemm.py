@@ -7,6 +7,7 @@ import torch
 from pacednegatives_amd import kernels as K
 
 M = int(os.environ.get("M", 139264))
+TILES = tuple(int(t) for t in os.environ.get("TILES", "128,256").split(","))
 SHAPES = [  # (name, ta, tb, epi, rows_out, cols_out, contraction)
     ("qkv   NT", 0, 0, K.EPI_BF16, M, 2304, 768),
     ("o     NT res", 0, 0, K.EPI_RES_DROP, M, 768, 768),
@@ -23,7 +24,7 @@ SHAPES = [  # (name, ta, tb, epi, rows_out, cols_out, contraction)
 
 def splits_for(rows, cols, contraction, tile):
     tiles = ((rows + tile - 1) // tile) * ((cols + tile - 1) // tile)
-    want = max(1, ((1024 if tile == 128 else 288) + tiles - 1) // tiles)
+    want = max(1, ((1024 if tile == 128 else 256) + tiles - 1) // tiles)
     return max(1, min(want, (contraction + 63) // 64))
 
 
@@ -32,14 +33,17 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
     res = {}
+    only = os.environ.get("ONLY")
     for name, ta, tb, epi, R, C, Kc in SHAPES:
+        if only and only not in name:
+            continue
         a = rn(Kc, R) if ta else rn(R, Kc)
         b = rn(Kc, C) if tb else rn(C, Kc)
         out = torch.zeros(R, C, device=dev, dtype=torch.float32 if epi in (K.EPI_F32, K.EPI_ATOMIC_F32) else torch.bfloat16)
         aux = rn(R, C) if epi in (K.EPI_RES_DROP, K.EPI_MASK) else None
         drop = 0.1 if epi in (K.EPI_RES_DROP, K.EPI_RELU_DROP) else 0.0
         for rnd in range(3):
-            for tile in (128, 256):
+            for tile in TILES:
                 K.gemm_set_tile(tile)
                 sp = 0 if epi == K.EPI_ATOMIC_F32 else 1
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -49,7 +53,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 res.setdefault((name, tile), []).append(e0.elapsed_time(e1) / 5)
-        for tile in (128, 256):
+        for tile in TILES:
             ms = min(res[(name, tile)])
             print(f"{name:16s} tile {tile}: {ms*1e3:8.1f} us  {2.0*R*C*Kc/ms/1e9:8.1f} TFLOP/s   (rounds {[round(x*1e3) for x in res[(name, tile)]]})", flush=True)
     K.gemm_set_tile(0)
