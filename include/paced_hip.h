@@ -54,7 +54,7 @@ int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
                     int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
                     float drop_p, uint32_t drop_seed, int splits, void* stream);
 
-/* Tile selection of paced_gemm_bf16: 0 = heuristic (default), 128 = 128x128 tiles, 256 = 256x256
+/* Tile selection of paced_gemm_bf16: 0 = heuristic (default), 64 = 64x64 tiles, 128 = 128x128 tiles, 256 = 256x256
  * phased tiles (one workgroup per CU, LDS ring).  Process-wide; meant for benchmarking and tests. */
 int paced_gemm_set_tile(int tile);
 

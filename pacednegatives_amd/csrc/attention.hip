@@ -46,6 +46,12 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* img, int rb, int dt, int
 // accumulator row index of register r for lane half h (32x32 C/D layout)
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// value of lane (l & ~3) + E for every lane l (DPP quad_perm broadcast)
+template <int E>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, E * 0x55, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ bf16x8 load8(const bf16* p, bool ok) {
     bf16x8 z;
 #pragma unroll
@@ -143,21 +149,26 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
         const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * S;
-        const bool pair_ok = (dbase & 1) == 0;            // keys (r, r+1) with r even then share one hash
+        const bool quad_ok = (S & 3) == 0;               // registers 4g..4g+3 hold 4 consecutive keys: one hash per quad
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float p0 = __expf(s[j][r] - m_new), p1 = __expf(s[j][r + 1] - m_new);
-                psum += p0 + p1;
-                float f0 = 1.f, f1 = 1.f;
+            for (int r = 0; r < 16; r += 4) {
+                float f[4] = {1.f, 1.f, 1.f, 1.f};
                 if (a.drop.thresh) {
-                    const int key = kt * 64 + 32 * j + acc_row(r, hh);      // even; register r+1 holds key+1
-                    if (pair_ok) drop_factor2(a.drop, dbase + key, f0, f1);
-                    else { f0 = drop_factor(a.drop, dbase + key); f1 = drop_factor(a.drop, dbase + key + 1); }
+                    const int key = kt * 64 + 32 * j + acc_row(r, hh);      // multiple of 4; registers r+1..r+3 hold key+1..key+3
+                    if (quad_ok) drop_factor4(a.drop, dbase + key, f);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = drop_factor(a.drop, dbase + key + e);
+                    }
                 }
-                s[j][r] = p0 * f0;
-                s[j][r + 1] = p1 * f1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = __expf(s[j][r + e] - m_new);
+                    psum += pe;
+                    s[j][r + e] = pe * f[e];
+                }
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -263,17 +274,41 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lDr, 0, ks, lane), vf[ks], dp, 0, 0, 0);
         }
         f32x16 pd;   // dropped probabilities (feeds dV); s becomes dS (feeds dK)
+        const uint64_t dnh = ((uint64_t)n * a.H + h) * S;
+        const bool quad_ok = (S & 3) == 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = acc_row(r, hh);
-            const int qq = qt * 32 + ql;
-            const bool ok = (qq < S) && (key < S);
-            const float p = ok ? __expf(s[r]) : 0.f;
-            float f = 1.f;
-            if (a.drop.thresh) f = drop_factor(a.drop, (((uint64_t)n * a.H + h) * S + min(qq, S - 1)) * S + keyc);
-            pd[r] = p * f;
-            const float ds = p * (dp[r] * f - ldel[ql]);
-            s[r] = ds;
+        for (int rg = 0; rg < 4; ++rg) {
+            // Registers 4rg..4rg+3 hold 4 consecutive queries at this lane's key; the hash covers 4
+            // consecutive KEYS of one query.  The 4 lanes of an aligned key quad therefore need the same
+            // 4 hashes: lane (l & 3) evaluates the one of query q4 + (l & 3) and a quad broadcast hands
+            // each to the other three.
+            uint32_t w0 = 0, w1 = 0;
+            const int q4 = qt * 32 + acc_row(4 * rg, hh);
+            if (a.drop.thresh && quad_ok)
+                paced_drop_words(a.drop.seed, ((dnh + min(q4 + (lane & 3), S - 1)) * S + (keyc & ~3)) >> 2, w0, w1);
+            uint32_t b0[4], b1[4];                     // words of queries q4 .. q4+3 (quad broadcasts of lanes 0..3)
+            b0[0] = quad_bcast<0>(w0); b0[1] = quad_bcast<1>(w0); b0[2] = quad_bcast<2>(w0); b0[3] = quad_bcast<3>(w0);
+            b1[0] = quad_bcast<0>(w1); b1[1] = quad_bcast<1>(w1); b1[2] = quad_bcast<2>(w1); b1[3] = quad_bcast<3>(w1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rg + e;
+                const int ql = acc_row(r, hh);
+                const int qq = qt * 32 + ql;
+                const bool ok = (qq < S) && (key < S);
+                const float p = ok ? __expf(s[r]) : 0.f;
+                float f = 1.f;
+                if (a.drop.thresh) {
+                    if (quad_ok) {
+                        const uint32_t wsel = (keyc & 2) ? b1[e] : b0[e];
+                        const uint32_t field = (keyc & 1) ? (wsel >> 16) : (wsel & 0xffffu);
+                        f = field >= a.drop.thresh ? a.drop.scale : 0.f;
+                    } else {
+                        f = drop_factor(a.drop, (dnh + min(qq, S - 1)) * S + keyc);
+                    }
+                }
+                pd[r] = p * f;
+                s[r] = p * (dp[r] * f - ldel[ql]);
+            }
         }
         if (a.dbias) {
             // Bias gradient = sums of dS along diagonals (key - query = const).  Rotate row ql of the
@@ -392,18 +427,23 @@ __global__ void __launch_bounds__(256, 3) enc_attn_bwd_dq_kernel(AttnArgs a) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lVr, 32 * j, ks, lane), dof[ks], dp, 0, 0, 0);
             }
             const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * S;
-            const bool pair_ok = (dbase & 1) == 0;
+            const bool quad_ok = (S & 3) == 0;
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int key = kt * 64 + 32 * j + acc_row(r, hh);          // even; register r+1 holds key+1
-                const float p0 = (key < S) ? __expf(s[r]) : 0.f, p1 = (key + 1 < S) ? __expf(s[r + 1]) : 0.f;
-                float f0 = 1.f, f1 = 1.f;
+            for (int r = 0; r < 16; r += 4) {
+                const int key = kt * 64 + 32 * j + acc_row(r, hh);          // multiple of 4; registers r+1..r+3 hold key+1..key+3
+                float f[4] = {1.f, 1.f, 1.f, 1.f};
                 if (a.drop.thresh) {
-                    if (pair_ok) drop_factor2(a.drop, dbase + key, f0, f1);
-                    else { f0 = drop_factor(a.drop, dbase + key); f1 = drop_factor(a.drop, dbase + key + 1); }
+                    if (quad_ok) drop_factor4(a.drop, dbase + key, f);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = drop_factor(a.drop, dbase + key + e);
+                    }
                 }
-                s[r] = p0 * (dp[r] * f0 - delta);
-                s[r + 1] = p1 * (dp[r + 1] * f1 - delta);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = (key + e < S) ? __expf(s[r + e]) : 0.f;
+                    s[r + e] = pe * (dp[r + e] * f[e] - delta);
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {

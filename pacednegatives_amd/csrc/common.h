@@ -43,18 +43,26 @@ __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32: RNE, NaN kept
 
 // ---------------------------------------------------------------------------------------------
-// Counter-based dropout.  One 32-bit hash serves TWO neighbouring elements (indices 2i and 2i+1 take
-// its low and high 16 bits); an element is KEPT when its 16-bit value >= thresh16 = round(p * 65536),
-// so the realised rate is p quantised to 1/65536, and kept values are scaled by 1/(1 - thresh16/65536).
-// Forward and backward kernels recompute the same decision from the same (seed, index), so no mask
-// is ever stored.
+// Counter-based dropout.  One hash evaluation serves FOUR neighbouring elements: element idx takes the
+// (idx & 3)-th 16-bit field of a 64-bit value derived from the quad number idx >> 2, and is KEPT when
+// its field >= thresh16 = round(p * 65536); so the realised rate is p quantised to 1/65536, and kept
+// values are scaled by 1/(1 - thresh16/65536).  Forward and backward kernels recompute the same
+// decision from the same (seed, index), so no mask is ever stored.
 __host__ __device__ __forceinline__ uint32_t paced_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
+// the two 32-bit words (fields 0,1 and fields 2,3) of quad number `quad`
+__host__ __device__ __forceinline__ void paced_drop_words(uint32_t seed, uint64_t quad, uint32_t& h0, uint32_t& h1) {
+    const uint32_t hi = (uint32_t)(quad >> 32) & 0xffffffu;
+    h0 = paced_mix32(((uint32_t)quad ^ seed) + hi * 0x9e3779u);     // 24 x 24-bit product: a full-rate multiply
+    h1 = (h0 ^ (h0 >> 13)) * 0xc2b2ae35u;
+    h1 ^= h1 >> 15;
+}
 __host__ __device__ __forceinline__ uint32_t paced_drop_bits(uint32_t seed, uint64_t idx) {
-    const uint32_t pair = (uint32_t)(idx >> 1), hi = (uint32_t)(idx >> 33);
-    const uint32_t h = paced_mix32((pair ^ seed) + hi * 0x9e3779b9u);
+    uint32_t h0, h1;
+    paced_drop_words(seed, idx >> 2, h0, h1);
+    const uint32_t h = (idx & 2) ? h1 : h0;
     return (idx & 1) ? (h >> 16) : (h & 0xffffu);
 }
 struct DropCfg {
@@ -76,13 +84,23 @@ __device__ __forceinline__ float drop_factor(const DropCfg& d, uint64_t idx) {
     if (d.thresh == 0) return 1.f;
     return paced_drop_bits(d.seed, idx) >= d.thresh ? d.scale : 0.f;
 }
-// factors of the aligned pair (idx even, idx+1) from ONE hash
-__device__ __forceinline__ void drop_factor2(const DropCfg& d, uint64_t idx_even, float& f0, float& f1) {
-    if (d.thresh == 0) { f0 = 1.f; f1 = 1.f; return; }
-    const uint32_t pair = (uint32_t)(idx_even >> 1), hi = (uint32_t)(idx_even >> 33);
-    const uint32_t h = paced_mix32((pair ^ d.seed) + hi * 0x9e3779b9u);
-    f0 = (h & 0xffffu) >= d.thresh ? d.scale : 0.f;
-    f1 = (h >> 16) >= d.thresh ? d.scale : 0.f;
+// factors of the aligned quad (idx4 a multiple of 4 .. idx4 + 3) from ONE hash evaluation
+__device__ __forceinline__ void drop_factor4(const DropCfg& d, uint64_t idx4, float (&f)[4]) {
+    if (d.thresh == 0) { f[0] = f[1] = f[2] = f[3] = 1.f; return; }
+    uint32_t h0, h1;
+    paced_drop_words(d.seed, idx4 >> 2, h0, h1);
+    f[0] = (h0 & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    f[1] = (h0 >> 16) >= d.thresh ? d.scale : 0.f;
+    f[2] = (h1 & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    f[3] = (h1 >> 16) >= d.thresh ? d.scale : 0.f;
+}
+// factors of 8 consecutive elements starting at a multiple of 4
+__device__ __forceinline__ void drop_factor8(const DropCfg& d, uint64_t idx4, float (&f)[8]) {
+    float a[4], b[4];
+    drop_factor4(d, idx4, a);
+    drop_factor4(d, idx4 + 4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
 }
 
 // ---------------------------------------------------------------------------------------------

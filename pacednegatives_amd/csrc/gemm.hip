@@ -23,6 +23,8 @@ constexpr int BK = 64;
 // Tile configurations.
 //   small:  128x128 output tile, 4 waves (2x2, 64x64 per wave), one LDS buffer, two barriers per K step;
 //           three workgroups per CU hide the staging latency.  Small outputs (decoder, ragged shapes).
+//   tiny:   64x64 output tile, otherwise as small: outputs too small to give every CU a 128x128 tile
+//           (the decoder's 2-token sequences).
 //   phased: 256x256 output tile, 8 waves (2x4), one workgroup per CU, all 160 KiB of LDS as a ring of
 //           half-tiles; see the kernel below.  moff/noff give the tile-relative origin of a wave's
 //           i-th / j-th 16x16 accumulator block.
@@ -31,6 +33,11 @@ struct CfgSmall {
     static constexpr int BM = 128, BN = 128, WGM = 2, WGN = 2, MI = 4, NJ = 4;
     static __device__ __forceinline__ int moff(int wm, int i) { return wm * 64 + i * 16; }
     static __device__ __forceinline__ int noff(int wn, int j) { return wn * 64 + j * 16; }
+};
+struct CfgTiny {
+    static constexpr int BM = 64, BN = 64, WGM = 2, WGN = 2, MI = 2, NJ = 2;
+    static __device__ __forceinline__ int moff(int wm, int i) { return wm * 32 + i * 16; }
+    static __device__ __forceinline__ int noff(int wn, int j) { return wn * 32 + j * 16; }
 };
 struct CfgPhased {
     static constexpr int BM = 256, BN = 256, WGM = 2, WGN = 4, MI = 8, NJ = 4;
@@ -43,7 +50,8 @@ namespace {
 // that lands at lane-linear LDS position g (16-byte units) of a tile image.
 //   K-contiguous operand : image [ROWS][64] bf16, 128-byte rows; chunk c of row r sits at c ^ ((r>>1)&7).
 //   K-strided operand    : image [64][ROWS] bf16; the 32-byte unit u of k-row k sits at u ^ h(k),
-//                          h(k) = (k&3) | ((k>>3)&1)<<2  (conflict-free ds_read_b64_tr_b16).
+//                          h(k) = (k&3) | ((k>>3)&1)<<2, masked to the units a k-row has
+//                          (conflict-free ds_read_b64_tr_b16 from 128 rows up).
 // With SPLIT (the phased kernel's B halves) image row r of a half is tile row (r>>5)*64 + (r&31): a
 // half holds one 32-row block out of every 64 rows, so that a wave's two 32-row slices (one per half)
 // are 64 CONSECUTIVE tile rows.
@@ -57,7 +65,7 @@ __device__ __forceinline__ uint32_t stage_offset(int g, int ld) {
     } else {
         constexpr int CPR = ROWS / 8;                 // 16-byte chunks per k-row
         const int k = g / CPR, cs = g % CPR;
-        const int hk = (k & 3) | (((k >> 3) & 1) << 2);
+        const int hk = ((k & 3) | (((k >> 3) & 1) << 2)) & (ROWS / 16 - 1);
         const int c = (((cs >> 1) ^ hk) << 1) | (cs & 1);
         const int csrc = SPLIT ? ((c >> 2) * 8 + (c & 3)) : c;
         return (uint32_t)(k * ld + csrc * 8) * 2u;
@@ -79,7 +87,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int rb, int kk, in
         constexpr int RB = ROWS * 2;                  // bytes per k-row
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
         const int u = rb >> 4;
-        const int hk = q | ((g & 1) << 2);
+        const int hk = (q | ((g & 1) << 2)) & (ROWS / 16 - 1);
         const int k0 = kk * 32 + 8 * g + q;
         const int addr0 = k0 * RB + ((u ^ hk) << 5) + p * 8;
         bf16x4 lo, hi;
@@ -107,15 +115,7 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, int m, int n, co
         return;
     }
     float f[4] = {1.f, 1.f, 1.f, 1.f};
-    if (EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP) {
-        if ((p.N & 1) == 0) {                       // di is even: one hash per two elements
-            drop_factor2(p.drop, di, f[0], f[1]);
-            drop_factor2(p.drop, di + 2, f[2], f[3]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) f[r] = drop_factor(p.drop, di + r);
-        }
-    }
+    if (EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP) drop_factor4(p.drop, di, f);     // N % 4 == 0: di is a multiple of 4
     if (EPI == EPI_RES_DROP || EPI == EPI_MASK) {
         const bf16x4 x = *reinterpret_cast<const bf16x4*>(p.aux + (size_t)m * p.ldaux + n);
 #pragma unroll
@@ -484,8 +484,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, int m0, int n
             }
             if (has_drop) {
                 float f[4];
-                drop_factor2(p.drop, drow + j * 16, f[0], f[1]);
-                drop_factor2(p.drop, drow + j * 16 + 2, f[2], f[3]);
+                drop_factor4(p.drop, drow + j * 16, f);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= f[r];
             }
@@ -671,7 +670,7 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const int ntm = (p.M + Cfg::BM - 1) / Cfg::BM, ntn = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int ktiles = (p.K + BK - 1) / BK;
     constexpr bool PHASED = std::is_same<Cfg, CfgPhased>::value;
-    const int slots = cu_count() * (PHASED ? 1 : 3);     // workgroups resident per CU
+    const int slots = cu_count() * (PHASED ? 1 : std::is_same<Cfg, CfgTiny>::value ? 6 : 3);     // workgroups resident per CU
     if (splits <= 0) {          // auto: fill the persistent grid once, keep >= 4 K steps per slice
         splits = 1;
         if (EPI == EPI_ATOMIC_F32 && ntm * ntn < slots) splits = slots / (ntm * ntn);
@@ -715,6 +714,10 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
                         (p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                          (!(EPI == EPI_RES_DROP || EPI == EPI_MASK) || (p.ldaux % 8 == 0 && ((uintptr_t)p.aux & 15) == 0)));
     if (large && rows16) return launch_cfg<CfgPhased, TA, TB, EPI>(p, splits, stream);
+    // fewer 128x128 tiles than CUs and no K split to make up for it: quarter-size tiles
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const bool tiny = g_force_tile == 64 || (g_force_tile == 0 && t128 < cu_count() && (EPI != EPI_ATOMIC_F32 || splits == 1));
+    if (tiny) return launch_cfg<CfgTiny, TA, TB, EPI>(p, splits, stream);
     return launch_cfg<CfgSmall, TA, TB, EPI>(p, splits, stream);
 }
 
@@ -736,7 +739,7 @@ int dispatch_epi(const GemmParams& p, int epi, int splits, hipStream_t s) {
 }  // namespace
 
 extern "C" int paced_gemm_set_tile(int tile) {
-    PACED_CHECK_ARG(tile == 0 || tile == 128 || tile == 256, "paced_gemm_set_tile: tile must be 0 (auto), 128 or 256");
+    PACED_CHECK_ARG(tile == 0 || tile == 64 || tile == 128 || tile == 256, "paced_gemm_set_tile: tile must be 0 (auto), 64, 128 or 256");
     g_force_tile = tile;
     return PACED_OK;
 }

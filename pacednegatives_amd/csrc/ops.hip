@@ -35,12 +35,10 @@ __global__ void __launch_bounds__(ROW_BLOCK) rmsnorm_fwd_kernel(const bf16* __re
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c * 8);
             const bf16x8 wv8 = *reinterpret_cast<const bf16x8*>(w + c * 8);
             bf16x8 o;
+            float df[8];
+            drop_factor8(drop, (uint64_t)row * d + c * 8, df);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = bf2f(v[j]) * rs * bf2f(wv8[j]) * out_scale;
-                f *= drop_factor(drop, (uint64_t)row * d + c * 8 + j);
-                o[j] = f2bf(f);
-            }
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(v[j]) * rs * bf2f(wv8[j]) * out_scale * df[j]);
             *reinterpret_cast<bf16x8*>(y + (size_t)row * d + c * 8) = o;
         }
     }
@@ -79,9 +77,11 @@ __global__ void __launch_bounds__(ROW_BLOCK) rmsnorm_bwd_kernel(const bf16* __re
                 const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * d + c * 8);
                 const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + (size_t)row * d + c * 8);
                 const bf16x8 wv8 = *reinterpret_cast<const bf16x8*>(w + c * 8);
+                float df[8];
+                drop_factor8(drop, (uint64_t)row * d + c * 8, df);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float dyo = bf2f(dv[j]) * drop_factor(drop, (uint64_t)row * d + c * 8 + j);
+                    const float dyo = bf2f(dv[j]) * df[j];
                     xh[i][j] = bf2f(xv[j]) * rs;
                     g[i][j] = dyo * bf2f(wv8[j]) * out_scale;
                     dwacc[i][j] += dyo * xh[i][j] * out_scale;
@@ -97,12 +97,14 @@ __global__ void __launch_bounds__(ROW_BLOCK) rmsnorm_bwd_kernel(const bf16* __re
                 bf16x8 r8;
                 if (dres) r8 = *reinterpret_cast<const bf16x8*>(dres + (size_t)row * d + c * 8);
                 bf16x8 o, o2;
+                float df2[8];
+                drop_factor8(drop2, (uint64_t)row * d + c * 8, df2);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float v = rs * (g[i][j] - xh[i][j] * dot);
                     if (dres) v += bf2f(r8[j]);
                     o[j] = f2bf(v);
-                    o2[j] = f2bf(bf2f(o[j]) * drop_factor(drop2, (uint64_t)row * d + c * 8 + j));
+                    o2[j] = f2bf(bf2f(o[j]) * df2[j]);
                 }
                 *reinterpret_cast<bf16x8*>(dx + (size_t)row * d + c * 8) = o;
                 if (dx2) *reinterpret_cast<bf16x8*>(dx2 + (size_t)row * d + c * 8) = o2;
@@ -136,8 +138,10 @@ __global__ void __launch_bounds__(ROW_BLOCK) embedding_fwd_kernel(const long lon
         for (int c = lane; c < nchunk; c += 64) {
             bf16x8 v = *reinterpret_cast<const bf16x8*>(table + (size_t)id * d + c * 8);
             if (drop.thresh) {
+                float df[8];
+                drop_factor8(drop, (uint64_t)row * d + c * 8, df);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * drop_factor(drop, (uint64_t)row * d + c * 8 + j));
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * df[j]);
             }
             *reinterpret_cast<bf16x8*>(out + (size_t)row * d + c * 8) = v;
         }
@@ -162,8 +166,10 @@ __global__ void __launch_bounds__(ROW_BLOCK) embedding_bwd_kernel(const long lon
 __global__ void __launch_bounds__(256) dropout_apply_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t n8, DropCfg drop) {
     for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n8; c += (size_t)gridDim.x * 256) {
         bf16x8 v = *reinterpret_cast<const bf16x8*>(x + c * 8);
+        float df[8];
+        drop_factor8(drop, c * 8, df);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * drop_factor(drop, c * 8 + j));
+        for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * df[j]);
         *reinterpret_cast<bf16x8*>(y + c * 8) = v;
     }
 }

@@ -32,7 +32,7 @@ def rnd(shape, seed, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[128, 256])
+@pytest.fixture(params=[64, 128, 256])
 def tile(request):
     K.gemm_set_tile(request.param)
     yield request.param
