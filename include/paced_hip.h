@@ -54,6 +54,15 @@ int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
                     int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
                     float drop_p, uint32_t drop_seed, int splits, void* stream);
 
+/* `batch` independent products of the same shape in one launch: member b uses A + b*strideA, B + b*strideB,
+ * C + b*strideC (strides in elements, multiples of 8).  Epilogues 0 (bf16), 4 (fp32) and 5 (fp32 atomic) only.
+ * Serves the per-head products of the decoder's cross-attention (HF modeling_t5.py:459-498 computes them as one
+ * projection followed by a per-head view; here each head's 64 x d_model weight slice is applied on its own). */
+int paced_gemm_bf16_batched(const void* A, const void* B, void* C,
+                            int M, int N, int K, int lda, int ldb, int ldc,
+                            int trans_a, int trans_b, int epilogue, float alpha, int splits,
+                            int batch, long long strideA, long long strideB, long long strideC, void* stream);
+
 /* Tile selection of paced_gemm_bf16: 0 = heuristic (default), 64 = 64x64 tiles, 128 = 128x128 tiles, 256 = 256x256
  * phased tiles (one workgroup per CU, LDS ring).  Process-wide; meant for benchmarking and tests. */
 int paced_gemm_set_tile(int tile);

@@ -19,6 +19,7 @@ SIGNATURES = {
     "paced_abi_version": (_i, []),
     "paced_last_error": (C.c_char_p, []),
     "paced_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _u32, _i, _vp]),
+    "paced_gemm_bf16_batched": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _ll, _ll, _ll, _vp]),
     "paced_gemm_set_tile": (_i, [_i]),
     "paced_rmsnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _u32, _vp]),
     "paced_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u32, _f, _u32, _vp]),

@@ -22,6 +22,8 @@ struct GemmParams {
     int M, N, K;
     int lda, ldb, ldc, ldaux;
     int k_per_split;   // multiple of BK
+    int batch;         // independent problems of the same shape; operand b starts strideX * b elements after operand 0
+    long long strideA, strideB, strideC;
     float alpha;       // scales acc before the epilogue
     float mask_scale;
     DropCfg drop;

@@ -103,15 +103,22 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int rb, int kk, in
     }
 }
 
+// output matrix of batch member b (fp32 for the fp32 / atomic epilogues, bf16 otherwise)
 template <int EPI>
-__device__ __forceinline__ void store_quad(const GemmParams& p, int m, int n, const f32x4& a) {
+__device__ __forceinline__ void* batch_c(const GemmParams& p, int b) {
+    constexpr int ES = (EPI == EPI_F32 || EPI == EPI_ATOMIC_F32) ? 4 : 2;
+    return reinterpret_cast<char*>(p.C) + (long long)b * p.strideC * ES;
+}
+
+template <int EPI>
+__device__ __forceinline__ void store_quad(const GemmParams& p, void* Cb, int m, int n, const f32x4& a) {
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
     const size_t ci = (size_t)m * p.ldc + n;
     const uint64_t di = (uint64_t)m * (uint64_t)p.N + n;   // dropout counter: logical (row, col)
     if (EPI == EPI_F32) {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + ci) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cb) + ci) = f32x4{v[0], v[1], v[2], v[3]};
         return;
     }
     float f[4] = {1.f, 1.f, 1.f, 1.f};
@@ -130,7 +137,7 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, int m, int n, co
     bf16x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + ci) = o;
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(Cb) + ci) = o;
 }
 
 template <class Cfg, bool TA, bool TB>
@@ -185,7 +192,7 @@ struct TileOps {
 
 // One unit of work of the persistent grid: an output tile and a slice of the contraction.
 struct WorkItem {
-    int m0, n0, kbeg, kend;
+    int m0, n0, kbeg, kend, b;
     __amdgpu_buffer_rsrc_t rA, rB;
 };
 
@@ -194,7 +201,11 @@ __device__ __forceinline__ WorkItem decode_item(const GemmParams& p, int L, int 
     constexpr int BM = Cfg::BM, BN = Cfg::BN;
     WorkItem it;
     const int ntiles = ntm * ntn;
-    const int split = L / ntiles, t = L - split * ntiles;
+    const int nsplit = (p.K + p.k_per_split - 1) / p.k_per_split;
+    const int per_batch = ntiles * nsplit;
+    it.b = L / per_batch;
+    const int r = L - it.b * per_batch;
+    const int split = r / ntiles, t = r - split * ntiles;
     // neighbouring items share an operand panel: walk the SHORTER tile dimension fastest
     int tm, tn;
     if (ntm >= ntn) { tm = t / ntn; tn = t - tm * ntn; } else { tn = t / ntm; tm = t - tn * ntm; }
@@ -204,8 +215,8 @@ __device__ __forceinline__ WorkItem decode_item(const GemmParams& p, int L, int 
     // Buffer descriptors: base at the tile's first row (or column), range = exactly the valid bytes,
     // so rows >= M/N and contraction rows >= K read as zero.
     const int rowsA = min(BM, p.M - it.m0), rowsB = min(BN, p.N - it.n0);
-    const bf16* baseA = TA ? p.A + it.m0 : p.A + (size_t)it.m0 * p.lda;
-    const bf16* baseB = TB ? p.B + it.n0 : p.B + (size_t)it.n0 * p.ldb;
+    const bf16* baseA = p.A + (long long)it.b * p.strideA + (TA ? (size_t)it.m0 : (size_t)it.m0 * p.lda);
+    const bf16* baseB = p.B + (long long)it.b * p.strideB + (TB ? (size_t)it.n0 : (size_t)it.n0 * p.ldb);
     const uint32_t recA = TA ? (uint32_t)(((size_t)(p.K - 1) * p.lda + rowsA) * 2) : (uint32_t)(((size_t)(rowsA - 1) * p.lda + p.K) * 2);
     const uint32_t recB = TB ? (uint32_t)(((size_t)(p.K - 1) * p.ldb + rowsB) * 2) : (uint32_t)(((size_t)(rowsB - 1) * p.ldb + p.K) * 2);
     it.rA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, recA, 0x00020000);
@@ -224,7 +235,7 @@ __device__ __forceinline__ int item_of(int b, int round, int G, int T) {
 }
 
 template <class Cfg, int EPI>
-__device__ __forceinline__ void epilogue(const GemmParams& p, int m0, int n0, int wm, int wn, int lane,
+__device__ __forceinline__ void epilogue(const GemmParams& p, void* Cb, int m0, int n0, int wm, int wn, int lane,
                                          f32x4 (&acc)[Cfg::MI][Cfg::NJ]) {
     constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
     if (EPI == EPI_TOPK_DENSE || EPI == EPI_TOPK_FILTER) {
@@ -252,7 +263,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m0, int n0, in
         return;
     }
     if (EPI == EPI_ATOMIC_F32) {
-        float* C = reinterpret_cast<float*>(p.C);
+        float* C = reinterpret_cast<float*>(Cb);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -274,7 +285,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m0, int n0, in
         for (int j = 0; j < NJ; ++j) {
             const int n = n0 + Cfg::noff(wn, j) + (lane >> 4) * 4;
             if (n >= p.N) continue;          // N is a multiple of 4 (checked on the host)
-            store_quad<EPI>(p, m, n, acc[i][j]);
+            store_quad<EPI>(p, Cb, m, n, acc[i][j]);
         }
     }
 }
@@ -318,7 +329,7 @@ __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_bf16_kernel(Gem
                 Ops::template multiply<NATURAL>(smem, 0, wm, wn, lane, acc);
                 __syncthreads();
             }
-            epilogue<Cfg, EPI>(p, it.m0, it.n0, wm, wn, lane, acc);
+            epilogue<Cfg, EPI>(p, batch_c<EPI>(p, it.b), it.m0, it.n0, wm, wn, lane, acc);
             L = item_of(b, ++round, G, total_items);
             if (L >= 0) it = decode_item<Cfg, TA, TB>(p, L, ntm, ntn);
         }
@@ -442,7 +453,7 @@ __device__ __forceinline__ int ring_wrap(int x) { return x >= 10 ? x - 10 : x; }
 // itself overwrites with its next two LDS-DMAs), so no barrier is involved.  Values are rounded to
 // bf16 before the transposition: C = bf16(aux + bf16(dropout(acc))) for the residual form.
 template <int EPI>
-__device__ __forceinline__ void epilogue_rows(const GemmParams& p, int m0, int n0, int wr, int wc, int lane,
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int m0, int n0, int wr, int wc, int lane,
                                               f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
     const int rr = lane >> 3, c = lane & 7;
     const int ncol = n0 + wc * 64 + c * 8;
@@ -505,7 +516,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, int m0, int n
                 for (int e = 0; e < 8; ++e) t[e] = bf2f(aux[i][q][e]) > 0.f ? t[e] : (bf16)0.f;
             }
             const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
-            if (m < p.M && col_ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + ncol) = t;
+            if (m < p.M && col_ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
         }
     }
 }
@@ -537,7 +548,7 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
     StepStream<TA, TB> st;
     st.wi = decode_item<CfgPhased, TA, TB>(p, L, ntm, ntn);
     st.k = st.wi.kbeg; st.round = 0; st.live = true;
-    int m0 = st.wi.m0, n0 = st.wi.n0;
+    int m0 = st.wi.m0, n0 = st.wi.n0, bz = st.wi.b;
     int nsteps = (st.wi.kend - st.wi.kbeg + BK - 1) / BK;
 
     {
@@ -628,16 +639,20 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
         if (EPI == EPI_BF16 || EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP || EPI == EPI_MASK) {
             char* s1 = sw + ring_wrap(base + 8) * HALF;      // the finished K step's B half 1 and A half 1 slots
             char* s2 = sw + ring_wrap(base + 9) * HALF;
-            epilogue_rows<EPI>(p, m0, n0, wr, wc, lane, acc, s1, s1 + 8192, s2, s2 + 8192);
+            epilogue_rows<EPI>(p, batch_c<EPI>(p, bz), m0, n0, wr, wc, lane, acc, s1, s1 + 8192, s2, s2 + 8192);
         } else {
-            epilogue<CfgPhased, EPI>(p, m0, n0, wr, wc, lane, acc);
+            epilogue<CfgPhased, EPI>(p, batch_c<EPI>(p, bz), m0, n0, wr, wc, lane, acc);
         }
         L = item_of(b, ++round, G, total_items);
         if (L < 0) break;
         {
             // position and K-step count of the next item (the stream decoded it already for its loads)
             const int ntiles = ntm * ntn;
-            const int split = L / ntiles, tt = L - split * ntiles;
+            const int nsplit = (p.K + p.k_per_split - 1) / p.k_per_split;
+            const int per_batch = ntiles * nsplit;
+            bz = L / per_batch;
+            const int rr = L - bz * per_batch;
+            const int split = rr / ntiles, tt = rr - split * ntiles;
             int tm, tn;
             if (ntm >= ntn) { tm = tt / ntn; tn = tt - tm * ntn; } else { tn = tt / ntm; tm = tt - tn * ntm; }
             m0 = tm * 256; n0 = tn * 256;
@@ -673,14 +688,14 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const int slots = cu_count() * (PHASED ? 1 : std::is_same<Cfg, CfgTiny>::value ? 6 : 3);     // workgroups resident per CU
     if (splits <= 0) {          // auto: fill the persistent grid once, keep >= 4 K steps per slice
         splits = 1;
-        if (EPI == EPI_ATOMIC_F32 && ntm * ntn < slots) splits = slots / (ntm * ntn);
+        if (EPI == EPI_ATOMIC_F32 && ntm * ntn * p.batch < slots) splits = slots / (ntm * ntn * p.batch);
         if (splits > ktiles / 4) splits = ktiles / 4 > 0 ? ktiles / 4 : 1;
     }
     if (splits > ktiles) splits = ktiles;
     const int tiles_per_split = (ktiles + splits - 1) / splits;
     p.k_per_split = tiles_per_split * BK;
     splits = (ktiles + tiles_per_split - 1) / tiles_per_split;
-    const int total = ntm * ntn * splits;
+    const int total = ntm * ntn * splits * p.batch;
     const int grid = total < slots ? total : slots;
     constexpr int smem = PHASED ? 163840 : (Cfg::BM + Cfg::BN) * BK * 2;
     if (smem > 65536) {
@@ -706,7 +721,7 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
     else if (g_force_tile == 256) large = true;
     else {
         // the 256x256 tile pays off once there is about one tile per CU (split slices count for atomics)
-        const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.batch;
         large = p.M >= 256 && p.N >= 256 && (t256 >= 200 || (EPI == EPI_ATOMIC_F32 && t256 >= 9));
     }
     // the phased kernel moves bf16 outputs (and their residual / mask operand) in 16-byte row pieces
@@ -715,7 +730,7 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
                          (!(EPI == EPI_RES_DROP || EPI == EPI_MASK) || (p.ldaux % 8 == 0 && ((uintptr_t)p.aux & 15) == 0)));
     if (large && rows16) return launch_cfg<CfgPhased, TA, TB, EPI>(p, splits, stream);
     // fewer 128x128 tiles than CUs and no K split to make up for it: quarter-size tiles
-    const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     const bool tiny = g_force_tile == 64 || (g_force_tile == 0 && t128 < cu_count() && (EPI != EPI_ATOMIC_F32 || splits == 1));
     if (tiny) return launch_cfg<CfgTiny, TA, TB, EPI>(p, splits, stream);
     return launch_cfg<CfgSmall, TA, TB, EPI>(p, splits, stream);
@@ -750,11 +765,19 @@ int paced_gemm_launch(const GemmParams& p, bool trans_a, bool trans_b, int epilo
     return dispatch_epi<true, true>(p, epilogue, splits, s);
 }
 
-extern "C" int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
-                               int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
-                               int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
-                               float drop_p, uint32_t drop_seed, int splits, void* stream) {
+static int gemm_entry(const void* A, const void* B, void* C, const void* aux,
+                      int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                      int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
+                      float drop_p, uint32_t drop_seed, int splits, void* stream,
+                      int batch, long long strideA, long long strideB, long long strideC) {
     PACED_CHECK_ARG(A && B && C, "paced_gemm_bf16: null operand");
+    PACED_CHECK_ARG(batch >= 1 && batch <= 65536, "paced_gemm_bf16_batched: batch must be in 1..65536 (got %d)", batch);
+    if (batch > 1) {
+        PACED_CHECK_ARG(epilogue == EPI_BF16 || epilogue == EPI_F32 || epilogue == EPI_ATOMIC_F32,
+                        "paced_gemm_bf16_batched: only the plain bf16, fp32 and atomic epilogues are batched");
+        PACED_CHECK_ARG(strideA % 8 == 0 && strideB % 8 == 0 && strideC % 8 == 0 && strideA >= 0 && strideB >= 0 && strideC >= 0,
+                        "paced_gemm_bf16_batched: strides must be non-negative multiples of 8 elements");
+    }
     PACED_CHECK_ARG(M > 0 && N > 0 && K > 0, "paced_gemm_bf16: M, N, K must be positive (got %d %d %d)", M, N, K);
     PACED_CHECK_ARG(epilogue >= 0 && epilogue < EPI_COUNT, "paced_gemm_bf16: unknown epilogue %d", epilogue);
     PACED_CHECK_ARG(!(trans_a && !trans_b), "paced_gemm_bf16: (trans_a=1, trans_b=0) is not built");
@@ -781,5 +804,22 @@ extern "C" int paced_gemm_bf16(const void* A, const void* B, void* C, const void
     p.alpha = alpha; p.mask_scale = mask_scale;
     p.drop = make_drop(drop_p, drop_seed);
     p.tk_cand = nullptr; p.tk_cnt = nullptr; p.tk_thr = nullptr; p.tk_cap = 0; p.tk_row_base = 0;
+    p.batch = batch; p.strideA = strideA; p.strideB = strideB; p.strideC = strideC;
     return paced_gemm_launch(p, trans_a != 0, trans_b != 0, epilogue, splits, (hipStream_t)stream);
+}
+
+extern "C" int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
+                               int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                               int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
+                               float drop_p, uint32_t drop_seed, int splits, void* stream) {
+    return gemm_entry(A, B, C, aux, M, N, K, lda, ldb, ldc, ldaux, trans_a, trans_b, epilogue, alpha, mask_scale,
+                      drop_p, drop_seed, splits, stream, 1, 0, 0, 0);
+}
+
+extern "C" int paced_gemm_bf16_batched(const void* A, const void* B, void* C,
+                                       int M, int N, int K, int lda, int ldb, int ldc,
+                                       int trans_a, int trans_b, int epilogue, float alpha, int splits,
+                                       int batch, long long strideA, long long strideB, long long strideC, void* stream) {
+    return gemm_entry(A, B, C, nullptr, M, N, K, lda, ldb, ldc, 0, trans_a, trans_b, epilogue, alpha, 1.f,
+                      0.f, 0, splits, stream, batch, strideA, strideB, strideC);
 }

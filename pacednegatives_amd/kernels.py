@@ -72,6 +72,25 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
     return c
 
 
+def gemm_batched(a, b, c, *, M, N, K, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, trans_a=False, trans_b=False,
+                 epilogue=EPI_BF16, alpha=1.0, splits=1):
+    """``batch`` products of one shape in one launch; member i reads a.data + i*stride_a, b.data + i*stride_b and writes
+    c.data + i*stride_c (strides and leading dimensions in elements).  The tensors only provide base pointers and dtypes."""
+    lib = _lib.load()
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    _chk(c, F32 if epilogue in (EPI_F32, EPI_ATOMIC_F32) else BF16, "c")
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(lib.paced_gemm_bf16_batched(_p(a), _p(b), _p(c), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), epilogue,
+                                           alpha, splits, batch, stride_a, stride_b, stride_c, _stream()), "paced_gemm_bf16_batched")
+    if prof is not None:
+        e1.record()
+        prof.append(((int(trans_a), int(trans_b), int(epilogue)), 2.0 * M * N * K * batch, e0, e1))
+    return c
+
+
 def gemm_set_tile(tile: int):
     """0 = heuristic, 128 or 256 = force that tile configuration (benchmarks and tests)."""
     _lib.check(_lib.load().paced_gemm_set_tile(tile), "paced_gemm_set_tile")

@@ -81,6 +81,45 @@ def test_gemm_many_tiles_per_workgroup_exact(ta, tb, tile):
         assert torch.equal(c2, want)
 
 
+def test_gemm_batched_per_head_products(tile):
+    """The three batched shapes of the decoder cross-attention: per-head slices of a projection matrix."""
+    R, H, dk, d = 72, 3, 64, 192                       # rows (sequences x 2), heads, head size, model width
+    q = ints((R, H * dk), -2, 2, 31)                   # per-head queries side by side
+    W = ints((H * dk, d), -2, 2, 32)                   # projection weight [out = H*dk, in = d]
+    Q, Wd = bf(q), bf(W)
+    # (i) out[r, h, :] = q[r, h*dk:(h+1)*dk] @ W[h*dk:(h+1)*dk, :]
+    out = torch.full((R, H * d), float("nan"), device=DEV)
+    K.gemm_batched(Q, Wd, out, M=R, N=d, K=dk, lda=H * dk, ldb=d, ldc=H * d, batch=H, stride_a=dk, stride_b=dk * d, stride_c=d,
+                   trans_b=True, epilogue=K.EPI_F32)
+    want = torch.einsum("rhk,hkd->rhd", q.view(R, H, dk), W.view(H, dk, d)).reshape(R, H * d)
+    assert torch.equal(out.cpu(), want)
+    # (ii) ctx[r, h*dk:(h+1)*dk] = z[r, h, :] @ W[h*dk:(h+1)*dk, :]^T
+    z = ints((R, H * d), -2, 2, 33)
+    ctx = torch.full((R, H * dk), float("nan"), device=DEV)
+    K.gemm_batched(bf(z), Wd, ctx, M=R, N=dk, K=d, lda=H * d, ldb=d, ldc=H * dk, batch=H, stride_a=d, stride_b=dk * d, stride_c=dk,
+                   epilogue=K.EPI_F32)
+    want = torch.einsum("rhd,hkd->rhk", z.view(R, H, d), W.view(H, dk, d)).reshape(R, H * dk)
+    assert torch.equal(ctx.cpu(), want)
+    # (iii) dW[h*dk:(h+1)*dk, :] += q[:, h]^T @ z[:, h, :]   (contraction over rows, atomic accumulation)
+    dW = torch.ones(H * dk, d, device=DEV)
+    K.gemm_batched(Q, bf(z), dW, M=dk, N=d, K=R, lda=H * dk, ldb=H * d, ldc=d, batch=H, stride_a=dk, stride_b=d, stride_c=dk * d,
+                   trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)
+    want = 1.0 + torch.einsum("rhk,rhd->hkd", q.view(R, H, dk), z.view(R, H, d)).reshape(H * dk, d)
+    assert torch.equal(dW.cpu(), want)
+
+
+def test_gemm_batched_large_tiles():
+    """Batched token-contraction product with bf16 output through the 256x256 kernel (one batch member per sequence)."""
+    Nb, S, Kc, d = 40, 256, 128, 768
+    w = ints((Nb, Kc, S), -2, 2, 34)
+    u = ints((Nb, Kc, d), -2, 2, 35)
+    out = torch.empty(Nb * S, d, device=DEV, dtype=torch.bfloat16)
+    K.gemm_batched(bf(w.view(Nb * Kc, S)), bf(u.view(Nb * Kc, d)), out, M=S, N=d, K=Kc, lda=S, ldb=d, ldc=d, batch=Nb,
+                   stride_a=Kc * S, stride_b=Kc * d, stride_c=S * d, trans_a=True, trans_b=True)
+    want = torch.einsum("nks,nkd->nsd", w, u).reshape(Nb * S, d)
+    assert torch.equal(out.float().cpu(), want.to(torch.bfloat16).float())
+
+
 def test_gemm_strided_views_and_alpha(tile):
     a = ints((200, 128), -2, 2, 3)
     b = ints((72, 128), -2, 2, 4)
