@@ -125,6 +125,22 @@ int paced_cross_attn_bwd(const void* qc, int ldq, const void* kv, int ldkv, int 
                          const void* dctx, int lddo, const float* lse, void* dqc, int lddq, void* dkv, int lddkv,
                          int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
 
+/* Decoder cross-attention WITHOUT key/value projections of the encoder states (same function as HF
+ * modeling_t5.py:459-498 for EncDecAttention with 2 target positions, re-associated): with C = 2H projected
+ * queries qk[n][c] = q[n][t][h] Wk_h (c = t*H + h, d wide; a batched paced_gemm_bf16_batched product),
+ *   s[c][k] = qk[c] . enc[n][k]     p = softmax_k(s)     z[n][c] = sum_k dropout(p)[c][k] enc[n][k]
+ * and the context of head h is z[c] Wv_h^T (another batched product).  enc [N*S, d] is read once; lse [N][C].
+ * Dropout counter: (n*C + c)*S + k.  Requires 2H <= 32 and d a multiple of 64 up to 1024. */
+int paced_cross2_fwd(const void* enc, int ld, const void* qk, void* z, float* lse,
+                     int N, int S, int H, int d, float drop_p, uint32_t drop_seed, void* stream);
+/* Backward of paced_cross2_fwd given dz [N][C][d]: dqk [N][C][d], and the factors of the encoder-state gradient
+ *   d enc[n][k] = sum_c ds[c][k] qk[c] + dropout(p)[c][k] dz[c]
+ * written for a later token-contraction product over all decoder layers: wslot + n*wstride holds ds then
+ * dropout(p), [2C][S] bf16; uslot + n*ustride holds qk then dz, [2C][d] bf16 (strides in elements). */
+int paced_cross2_bwd(const void* enc, int ld, const void* qk, const void* dz, const void* z, const float* lse,
+                     void* dqk, void* wslot, long long wstride, void* uslot, long long ustride,
+                     int N, int S, int H, int d, float drop_p, uint32_t drop_seed, void* stream);
+
 /* ---- loss: nn.CrossEntropyLoss(ignore_index, reduction='none'), lceT5.py:110,117-118 ----------
  * loss[r] = logsumexp(logits[r,:]) - logits[r,label[r]] (0 for ignored rows);
  * dlogits (bf16, may be NULL) = (softmax - onehot) * gscale. */

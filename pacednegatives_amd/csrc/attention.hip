@@ -682,6 +682,298 @@ __global__ void __launch_bounds__(256) cross_attn_bwd_kernel(const bf16* __restr
     }
 }
 
+}  // namespace
+
+// ============================================ decoder cross-attention without key/value projections
+// (kernel templates stay outside the anonymous namespace so that their host stubs are emitted)
+// With 2 target positions per sequence the projections of the S encoder states are the wrong side to
+// multiply: scores = (q_h Wk_h) . e_s and ctx_h = (sum_s p_s e_s) Wv_h^T give the same result from
+// C = 2H "projected queries" qk[c] = q_c Wk_h (d_model wide, c = t*H + h) per sequence, so the encoder
+// output e [S, d] is read once and no [S, 2*H*64] key/value tensor exists.  Per sequence this is an
+// attention with C <= 32 queries, one shared key/value set (e itself) and head size d:
+//     s[c, k] = qk[c] . e[k]        p = softmax_k(s)        z[c] = sum_k dropout(p)[c, k] e[k]
+// One 256-thread workgroup per sequence; wave w owns the 64-wide feature slices j = w, w+4, ... of d.
+// Per tile of 32 keys: the [32][d] tile is staged as d/64 tr images; every wave multiplies its slices
+// (32x32x16 MFMA, lane = query), the four partial score tiles are summed through LDS, every wave runs
+// the (identical) online softmax, and accumulates z^T for its slices straight from the score registers.
+constexpr int X_MAXF = 4;                 // feature slices per wave: d <= 1024
+
+// A-operand fragment (32 keys x 16 features) read by rows from a tr image (bank conflicts accepted:
+// the kernel is bound by the HBM read of e)
+__device__ __forceinline__ bf16x8 frag_rows_tr(const char* img, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(img + tr_img_off(lane & 31, 2 * ks + (lane >> 5)));
+}
+
+struct CrossArgs {
+    const bf16* enc; int ld;        // [N*S, d] rows n*S + s
+    const bf16* qk;                 // [N, C, d]
+    const bf16* dz;                 // [N, C, d]   (backward)
+    const bf16* z_in;               // [N, C, d]   (backward: forward output)
+    bf16* z;                        // forward output
+    bf16* dqk;                      // [N, C, d]   (backward output)
+    float* lse;                     // [N, C]
+    bf16* wslot; long long wstride; // backward: ds rows then dropped-p rows, [2C][S] per sequence, sequence stride in elements
+    bf16* uslot; long long ustride; // backward: copies of qk then dz, [2C][d] per sequence
+    int N, S, C, d;
+    DropCfg drop;
+};
+
+// sums the four waves' 32x32 partial tiles; `part` holds 4 * 16 * 64 floats
+__device__ __forceinline__ void reduce_tiles(float* part, int w, int lane, f32x16& s) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(w * 16 + r) * 64 + lane] = s[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        s[r] = part[(0 * 16 + r) * 64 + lane] + part[(1 * 16 + r) * 64 + lane] + part[(2 * 16 + r) * 64 + lane] + part[(3 * 16 + r) * 64 + lane];
+}
+
+template <int NF>
+__global__ void __launch_bounds__(256) cross2_fwd_kernel(CrossArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NB = a.d >> 6;                                   // 64-wide feature slices
+    float* part = reinterpret_cast<float*>(smem + NB * 4096);  // 16 KiB
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5, c = lane & 31;
+    const int n = blockIdx.x, S = a.S, C = a.C, d = a.d;
+    const int nf = (NB - w + 3) >> 2;                          // slices of this wave
+    const bf16* E = a.enc + (size_t)n * S * a.ld;
+    const bf16* qrow = a.qk + ((size_t)n * C + min(c, C - 1)) * d;
+
+    bf16x8 qf[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[f][ks] = load8(qrow + (w + 4 * f) * 64 + 16 * ks + 8 * hh, f < nf && c < C);
+
+    f32x16 zacc[NF][2];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { zacc[f][0][r] = 0.f; zacc[f][1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const uint64_t dbase = ((uint64_t)n * C + min(c, C - 1)) * S;
+    const bool quad_ok = (S & 3) == 0;
+
+    const int ntile = (S + 31) / 32;
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();
+        for (int j = 0; j < NB; ++j) stage_tile<32>(E + j * 64, a.ld, kt * 32, S, nullptr, smem + j * 4096);
+        __syncthreads();
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            if (f < nf) {
+                const char* img = smem + (w + 4 * f) * 4096;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_tr(img, ks, lane), qf[f][ks], s, 0, 0, 0);
+            }
+        reduce_tiles(part, w, lane, s);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (kt * 32 + acc_row(r, hh) >= S) s[r] = -INFINITY;
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            float fct[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.drop.thresh) {
+                const int key = kt * 32 + acc_row(r, hh);
+                if (quad_ok) drop_factor4(a.drop, dbase + key, fct);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fct[e] = drop_factor(a.drop, dbase + min(key + e, S - 1));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = __expf(s[r + e] - m_new);
+                psum += pe;
+                s[r + e] = pe * fct[e];
+            }
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            if (f < nf) {
+                const char* img = smem + (w + 4 * f) * 4096;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { zacc[f][0][r] *= alpha; zacc[f][1][r] *= alpha; }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = pack8(s, s2);
+                    zacc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(img, 16 * s2, 0, lane), pf, zacc[f][0], 0, 0, 0);
+                    zacc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(img, 16 * s2, 1, lane), pf, zacc[f][1], 0, 0, 0);
+                }
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (c < C) {
+        if (hh == 0 && w == 0) a.lse[(size_t)n * C + c] = m_run + __logf(l_tot);
+        bf16* zrow = a.z + ((size_t)n * C + c) * d;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            if (f < nf) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        bf16x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = f2bf(zacc[f][dt][4 * rg + e] * inv);
+                        *reinterpret_cast<bf16x4*>(zrow + (w + 4 * f) * 64 + dt * 32 + 8 * rg + 4 * hh) = v;
+                    }
+            }
+    }
+}
+
+// Backward of the above for one sequence: with dp[c,k] = dz[c] . e[k], delta[c] = dz[c] . z[c],
+//     ds = p (dp * mask - delta)        dqk[c] = sum_k ds[c,k] e[k]
+// and the two [C][S] factors ds and dropout(p) are written out (bf16) together with copies of qk and
+// dz: the gradient of e, sum_c ds[c,k] qk[c] + dropout(p)[c,k] dz[c], is a token-contraction product
+// that the caller takes over ALL decoder layers at once (one batched GEMM instead of a read-modify-write
+// of the [S, d] gradient per layer).
+template <int NF>
+__global__ void __launch_bounds__(256) cross2_bwd_kernel(CrossArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NB = a.d >> 6;
+    float* part = reinterpret_cast<float*>(smem + NB * 4096);  // 16 KiB
+    float* dred = part + 4 * 16 * 64;                          // 4 * 32 floats
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5, c = lane & 31;
+    const int n = blockIdx.x, S = a.S, C = a.C, d = a.d;
+    const int nf = (NB - w + 3) >> 2;
+    const int cc = min(c, C - 1);
+    const bf16* E = a.enc + (size_t)n * S * a.ld;
+    const size_t rowoff = ((size_t)n * C + cc) * d;
+
+    bf16x8 qf[NF][4], gf[NF][4];
+    float delta = 0.f;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bool ok = f < nf && c < C;
+            const size_t off = rowoff + (w + 4 * f) * 64 + 16 * ks + 8 * hh;
+            qf[f][ks] = load8(a.qk + off, ok);
+            gf[f][ks] = load8(a.dz + off, ok);
+            const bf16x8 zv = load8(a.z_in + off, ok);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += bf2f(gf[f][ks][j]) * bf2f(zv[j]);
+            if (ok) {   // copies for the caller's gradient-of-e product: rows [0, C) = qk, rows [C, 2C) = dz
+                bf16* u = a.uslot + (size_t)n * a.ustride + (size_t)c * d + (w + 4 * f) * 64 + 16 * ks + 8 * hh;
+                *reinterpret_cast<bf16x8*>(u) = qf[f][ks];
+                *reinterpret_cast<bf16x8*>(u + (size_t)C * d) = gf[f][ks];
+            }
+        }
+    delta += __shfl_xor(delta, 32, 64);
+    if (hh == 0) dred[w * 32 + c] = delta;
+    __syncthreads();
+    delta = dred[c] + dred[32 + c] + dred[64 + c] + dred[96 + c];
+    const float lse = a.lse[(size_t)n * C + cc];
+
+    f32x16 qacc[NF][2];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { qacc[f][0][r] = 0.f; qacc[f][1][r] = 0.f; }
+    const uint64_t dbase = ((uint64_t)n * C + cc) * S;
+    const bool quad_ok = (S & 3) == 0;
+    bf16* wrow = a.wslot + (size_t)n * a.wstride + (size_t)cc * S;
+
+    const int ntile = (S + 31) / 32;
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();
+        for (int j = 0; j < NB; ++j) stage_tile<32>(E + j * 64, a.ld, kt * 32, S, nullptr, smem + j * 4096);
+        __syncthreads();
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            if (f < nf) {
+                const char* img = smem + (w + 4 * f) * 4096;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 ef = frag_rows_tr(img, ks, lane);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, qf[f][ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, gf[f][ks], dp, 0, 0, 0);
+                }
+            }
+        reduce_tiles(part, w, lane, s);
+        __syncthreads();
+        reduce_tiles(part, w, lane, dp);
+        f32x16 pd;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            const int key = kt * 32 + acc_row(r, hh);
+            float fct[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.drop.thresh) {
+                if (quad_ok) drop_factor4(a.drop, dbase + key, fct);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fct[e] = drop_factor(a.drop, dbase + min(key + e, S - 1));
+                }
+            }
+            bf16x4 dsv, pdv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pe = (key + e < S) ? __expf(s[r + e] - lse) : 0.f;
+                pd[r + e] = pe * fct[e];
+                s[r + e] = pe * (dp[r + e] * fct[e] - delta);
+                dsv[e] = f2bf(s[r + e]);
+                pdv[e] = f2bf(pd[r + e]);
+            }
+            if (w == 0 && c < C) {
+                if (quad_ok && key + 3 < S) {
+                    *reinterpret_cast<bf16x4*>(wrow + key) = dsv;
+                    *reinterpret_cast<bf16x4*>(wrow + (size_t)C * S + key) = pdv;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (key + e < S) { wrow[key + e] = dsv[e]; wrow[(size_t)C * S + key + e] = pdv[e]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            if (f < nf) {
+                const char* img = smem + (w + 4 * f) * 4096;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 df = pack8(s, s2);
+                    qacc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(img, 16 * s2, 0, lane), df, qacc[f][0], 0, 0, 0);
+                    qacc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(img, 16 * s2, 1, lane), df, qacc[f][1], 0, 0, 0);
+                }
+            }
+    }
+    if (c < C) {
+        bf16* qrow = a.dqk + ((size_t)n * C + c) * d;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            if (f < nf) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        bf16x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = f2bf(qacc[f][dt][4 * rg + e]);
+                        *reinterpret_cast<bf16x4*>(qrow + (w + 4 * f) * 64 + dt * 32 + 8 * rg + 4 * hh) = v;
+                    }
+            }
+    }
+}
+
+namespace {
+
 int check_common(const char* fn, int N, int S, int H, int dk) {
     if (dk != DK) { paced_set_error("%s: head size %d is not built (only 64)", fn, dk); return PACED_ERR_ARG; }
     if (N <= 0 || S <= 0 || H <= 0) { paced_set_error("%s: bad shape N=%d S=%d H=%d", fn, N, S, H); return PACED_ERR_ARG; }
@@ -774,4 +1066,68 @@ extern "C" int paced_cross_attn_bwd(const void* qc, int ldq, const void* kv, int
                        (bf16*)dqc, lddq, (bf16*)dkv, lddkv, N, S, H, make_drop(drop_p, drop_seed));
     PACED_CHECK_LAUNCH();
     return PACED_OK;
+}
+
+template <int NF, bool BWD>
+static int launch_cross2(const CrossArgs& a, int smem, hipStream_t stream) {
+    static bool attr_set = false;     // one flag per instantiation
+    if (!attr_set && smem > 65536) {
+        hipError_t e;
+        if (BWD) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross2_bwd_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096 + 16384 + 512);
+        else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross2_fwd_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096 + 16384 + 512);
+        if (e != hipSuccess) { paced_set_error("cross-attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PACED_ERR_HIP; }
+        attr_set = true;
+    }
+    if (BWD) hipLaunchKernelGGL((cross2_bwd_kernel<NF>), dim3(a.N), dim3(256), smem, stream, a);
+    else hipLaunchKernelGGL((cross2_fwd_kernel<NF>), dim3(a.N), dim3(256), smem, stream, a);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+static int check_cross2(const char* fn, int N, int S, int H, int d) {
+    if (N <= 0 || S <= 0 || H <= 0) { paced_set_error("%s: bad shape N=%d S=%d H=%d", fn, N, S, H); return PACED_ERR_ARG; }
+    if (2 * H > 32) { paced_set_error("%s: 2*H = %d projected queries exceed the 32 one MFMA tile holds", fn, 2 * H); return PACED_ERR_ARG; }
+    if (d % 64 != 0 || d > 64 * 4 * X_MAXF || d <= 0) { paced_set_error("%s: d_model %d must be a multiple of 64 up to %d", fn, d, 64 * 4 * X_MAXF); return PACED_ERR_ARG; }
+    return PACED_OK;
+}
+
+extern "C" int paced_cross2_fwd(const void* enc, int ld, const void* qk, void* z, float* lse,
+                                int N, int S, int H, int d, float drop_p, uint32_t drop_seed, void* stream) {
+    if (int e = check_cross2("paced_cross2_fwd", N, S, H, d)) return e;
+    PACED_CHECK_ARG(enc && qk && z && lse, "paced_cross2_fwd: null operand");
+    PACED_CHECK_ARG(ld % 8 == 0 && ld >= d, "paced_cross2_fwd: the row stride of enc must be a multiple of 8 and >= d");
+    CrossArgs a = {};
+    a.enc = (const bf16*)enc; a.ld = ld; a.qk = (const bf16*)qk; a.z = (bf16*)z; a.lse = lse;
+    a.N = N; a.S = S; a.C = 2 * H; a.d = d; a.drop = make_drop(drop_p, drop_seed);
+    const int smem = (d / 64) * 4096 + 16384;
+    switch ((d / 64 + 3) / 4) {
+        case 1: return launch_cross2<1, false>(a, smem, (hipStream_t)stream);
+        case 2: return launch_cross2<2, false>(a, smem, (hipStream_t)stream);
+        case 3: return launch_cross2<3, false>(a, smem, (hipStream_t)stream);
+        default: return launch_cross2<4, false>(a, smem, (hipStream_t)stream);
+    }
+}
+
+extern "C" int paced_cross2_bwd(const void* enc, int ld, const void* qk, const void* dz, const void* z, const float* lse,
+                                void* dqk, void* wslot, long long wstride, void* uslot, long long ustride,
+                                int N, int S, int H, int d, float drop_p, uint32_t drop_seed, void* stream) {
+    if (int e = check_cross2("paced_cross2_bwd", N, S, H, d)) return e;
+    PACED_CHECK_ARG(enc && qk && dz && z && lse && dqk && wslot && uslot, "paced_cross2_bwd: null operand");
+    PACED_CHECK_ARG(ld % 8 == 0 && ld >= d, "paced_cross2_bwd: the row stride of enc must be a multiple of 8 and >= d");
+    PACED_CHECK_ARG(wstride >= (long long)4 * H * S && ustride >= (long long)4 * H * d && ustride % 8 == 0,
+                    "paced_cross2_bwd: per-sequence strides of the factor buffers are too small");
+    PACED_CHECK_ARG(((uintptr_t)uslot & 15) == 0 && ((uintptr_t)wslot & 7) == 0 && (S % 4 != 0 || wstride % 4 == 0),
+                    "paced_cross2_bwd: factor buffers are misaligned");
+    CrossArgs a = {};
+    a.enc = (const bf16*)enc; a.ld = ld; a.qk = (const bf16*)qk; a.dz = (const bf16*)dz; a.z_in = (const bf16*)z;
+    a.lse = const_cast<float*>(lse); a.dqk = (bf16*)dqk;
+    a.wslot = (bf16*)wslot; a.wstride = wstride; a.uslot = (bf16*)uslot; a.ustride = ustride;
+    a.N = N; a.S = S; a.C = 2 * H; a.d = d; a.drop = make_drop(drop_p, drop_seed);
+    const int smem = (d / 64) * 4096 + 16384 + 512;
+    switch ((d / 64 + 3) / 4) {
+        case 1: return launch_cross2<1, true>(a, smem, (hipStream_t)stream);
+        case 2: return launch_cross2<2, true>(a, smem, (hipStream_t)stream);
+        case 3: return launch_cross2<3, true>(a, smem, (hipStream_t)stream);
+        default: return launch_cross2<4, true>(a, smem, (hipStream_t)stream);
+    }
 }

@@ -259,6 +259,31 @@ def cross_attn_bwd(qc, kv, ctx, dctx, lse, dqc, dkv, N, S, H, *, drop_p=0.0, dro
                                         N, S, H, 64, drop_p, drop_seed, _stream()), "paced_cross_attn_bwd")
 
 
+def cross2_fwd(enc, qk, z, lse, N, S, H, *, drop_p=0.0, drop_seed=0):
+    """Projection-free decoder cross-attention: enc [N*S, d], qk/z [N*2, H*d] (row n*2+t, head h at column h*d), lse [N*2H]."""
+    lib = _lib.load()
+    _chk(enc, BF16, "enc"); _chk(qk, BF16, "qk"); _chk(z, BF16, "z"); _chk(lse, F32, "lse")
+    d = enc.shape[1]
+    assert enc.shape[0] == N * S and tuple(qk.shape) == (N * 2, H * d) and tuple(z.shape) == (N * 2, H * d)
+    assert qk.is_contiguous() and z.is_contiguous() and lse.is_contiguous() and lse.numel() == N * 2 * H
+    _lib.check(lib.paced_cross2_fwd(_p(enc), _rows2d(enc, "enc"), _p(qk), _p(z), _p(lse), N, S, H, d, drop_p, drop_seed, _stream()),
+               "paced_cross2_fwd")
+    return z
+
+
+def cross2_bwd(enc, qk, dz, z, lse, dqk, wslot, wstride, uslot, ustride, N, S, H, *, drop_p=0.0, drop_seed=0):
+    """Backward of cross2_fwd; wslot/uslot are views whose first element is this layer's slot of the factor buffers."""
+    lib = _lib.load()
+    for t, n in ((enc, "enc"), (qk, "qk"), (dz, "dz"), (z, "z"), (dqk, "dqk"), (wslot, "wslot"), (uslot, "uslot")):
+        _chk(t, BF16, n)
+    _chk(lse, F32, "lse")
+    d = enc.shape[1]
+    for t in (qk, dz, z, dqk):
+        assert tuple(t.shape) == (N * 2, H * d) and t.is_contiguous()
+    _lib.check(lib.paced_cross2_bwd(_p(enc), _rows2d(enc, "enc"), _p(qk), _p(dz), _p(z), _p(lse), _p(dqk), _p(wslot), wstride,
+                                    _p(uslot), ustride, N, S, H, d, drop_p, drop_seed, _stream()), "paced_cross2_bwd")
+
+
 def cross_entropy(logits, labels, loss, dlogits=None, *, ignore_index=-100, gscale=1.0):
     lib = _lib.load()
     _chk(logits, F32, "logits"); _chk(labels, I64, "labels"); _chk(loss, F32, "loss"); _chk(dlogits, BF16, "dlogits")

@@ -77,6 +77,8 @@ class _DecLayerSaved:
     xn2: torch.Tensor = None
     rstd2: torch.Tensor = None
     qc: torch.Tensor = None
+    qk: torch.Tensor = None
+    z: torch.Tensor = None
     kv: torch.Tensor = None
     cctx: torch.Tensor = None
     clse: torch.Tensor = None
@@ -94,6 +96,7 @@ class ForwardState:
     T: int = 2
     p: float = 0.0
     seed: int = 0
+    cross2: bool = False
     ids: torch.Tensor = None
     dec_ids: torch.Tensor = None
     enc_layers: List[_EncLayerSaved] = field(default_factory=list)
@@ -124,6 +127,7 @@ class T5Engine:
         self.dims, self.params = dims, params
         self.device = params.device
         self._bucket_cache: Dict[int, torch.Tensor] = {}
+        self.force_kv_projection = False      # tests: take the explicit K/V projection path of the cross-attention
         self._bucket_dec = torch.tensor([0, 1], dtype=torch.int32, device=self.device)   # offsets 0 and -1 (HF:244-249)
         dec_b = relative_position_bucket(torch.tensor([0, -1]), False, dims.num_buckets, dims.max_distance)
         assert dec_b.tolist() == [0, 1]
@@ -139,6 +143,13 @@ class T5Engine:
 
     def _seed(self, st: ForwardState, site: int, layer: int = 0, dec: bool = False) -> int:
         return _mix(st.seed, site + 16 * layer + (4096 if dec else 0))
+
+    def _cross2_ok(self, S: int) -> bool:
+        """The projection-free cross-attention kernels need 2H <= 32 queries per sequence, d_model a multiple of 64 up to
+        1024 and (for the token-contraction product of the backward) S a multiple of 8; other shapes take the K/V path."""
+        dm = self.dims
+        return (2 * dm.num_heads <= 32 and dm.d_model % 64 == 0 and dm.d_model <= 1024 and S % 8 == 0
+                and dm.inner == dm.num_heads * 64 and not self.force_kv_projection)
 
     def _empty(self, rows, cols, dtype=BF16):
         return torch.empty(rows, cols, dtype=dtype, device=self.device)
@@ -168,8 +179,10 @@ class T5Engine:
         dec_ids = dec_ids.masked_fill(dec_ids == -100, 0).contiguous().view(-1)
         d, I, ff, H = dims.d_model, dims.inner, dims.d_ff, dims.num_heads
         M, Md = N * S, N * 2
+        dk = I // H
         st = ForwardState(N=N, S=S, p=float(drop_p), seed=int(seed), ids=ids, dec_ids=dec_ids)
         p = st.p
+        cross2 = st.cross2 = self._cross2_ok(S)
 
         # ---- encoder
         st.bucket_enc = self._buckets(S)
@@ -228,11 +241,22 @@ class T5Engine:
             K.rmsnorm_fwd(g1, P.w(pre + "ln2"), xn2, rstd2, eps=dims.eps)
             qc = self._empty(Md, I)
             K.gemm(xn2, P.w(pre + "cq"), qc)
-            kv = self._empty(M, 2 * I)
-            K.gemm(enc, P.w(pre + "ckv"), kv)
             cctx = self._empty(Md, I)
             clse = torch.empty(N * H * 2, dtype=F32, device=self.device)
-            K.cross_attn_fwd(qc, kv, cctx, clse, N, S, H, drop_p=p, drop_seed=self._seed(st, _SITE_CATT, l, True))
+            kv = qk = z = None
+            if cross2:
+                # scores = (q_h Wk_h) . enc and ctx_h = (p . enc) Wv_h^T: the encoder states are never projected
+                Wckv = P.w(pre + "ckv")
+                qk, z = self._empty(Md, H * d), self._empty(Md, H * d)
+                K.gemm_batched(qc, Wckv[:I], qk, M=Md, N=d, K=dk, lda=I, ldb=d, ldc=H * d, batch=H,
+                               stride_a=dk, stride_b=dk * d, stride_c=d, trans_b=True)
+                K.cross2_fwd(enc, qk, z, clse, N, S, H, drop_p=p, drop_seed=self._seed(st, _SITE_CATT, l, True))
+                K.gemm_batched(z, Wckv[I:], cctx, M=Md, N=dk, K=d, lda=H * d, ldb=d, ldc=I, batch=H,
+                               stride_a=d, stride_b=dk * d, stride_c=dk)
+            else:
+                kv = self._empty(M, 2 * I)
+                K.gemm(enc, P.w(pre + "ckv"), kv)
+                K.cross_attn_fwd(qc, kv, cctx, clse, N, S, H, drop_p=p, drop_seed=self._seed(st, _SITE_CATT, l, True))
             g2 = self._empty(Md, d)
             K.gemm(cctx, P.w(pre + "co"), g2, epilogue=K.EPI_RES_DROP, aux=g1, drop_p=p, drop_seed=self._seed(st, _SITE_CATT_OUT, l, True))
             xn3, rstd3 = self._empty(Md, d), torch.empty(Md, dtype=F32, device=self.device)
@@ -244,6 +268,7 @@ class T5Engine:
             if save:
                 sv.g_in, sv.xn, sv.rstd1, sv.qkv, sv.ctx, sv.g1 = g, xn, rstd1, qkv, ctx, g1
                 sv.xn2, sv.rstd2, sv.qc, sv.kv, sv.cctx, sv.clse, sv.g2 = xn2, rstd2, qc, kv, cctx, clse, g2
+                sv.qk, sv.z = qk, z
                 sv.xn3, sv.rstd3, sv.act = xn3, rstd3, act
                 st.dec_layers.append(sv)
             g = g3
@@ -292,6 +317,8 @@ class T5Engine:
                       out_scale=d ** -0.5, drop_p=p, drop_seed=self._seed(st, _SITE_DEC_FINAL),
                       drop2_p=p, drop2_seed=self._seed(st, _SITE_FF_OUT, nd - 1, True))
         d_enc = None
+        xW = xU = None
+        dk = I // H
         for l in reversed(range(nd)):
             pre = f"dec.{l}."
             sv = st.dec_layers[l]
@@ -312,16 +339,37 @@ class T5Engine:
             self._dweight(z, sv.cctx, pre + "co")
             dcctx = self._empty(Md, I)
             K.gemm(z, P.w(pre + "co"), dcctx, trans_b=True)
-            dqc, dkv = self._empty(Md, I), self._empty(M, 2 * I)
-            K.cross_attn_bwd(sv.qc, sv.kv, sv.cctx, dcctx, sv.clse, dqc, dkv, N, S, H,
-                             drop_p=p, drop_seed=self._seed(st, _SITE_CATT, l, True))
-            self._dweight(dqc, sv.xn2, pre + "cq")
-            self._dweight(dkv, st.enc_out, pre + "ckv")
-            if d_enc is None:
-                d_enc = self._empty(M, d)
-                K.gemm(dkv, P.w(pre + "ckv"), d_enc, trans_b=True)
+            dqc = self._empty(Md, I)
+            if st.cross2:
+                Wckv, gckv = P.w(pre + "ckv"), P.grad(pre + "ckv")
+                C2 = 2 * H
+                if xW is None:      # factors of d enc over all decoder layers: [N][nd*2C][S] and [N][nd*2C][d]
+                    xW = torch.empty(N, nd * 2 * C2, S, dtype=BF16, device=self.device)
+                    xU = torch.empty(N, nd * 2 * C2, d, dtype=BF16, device=self.device)
+                # dWv_h += dcctx_h^T z_h ;  dz_h = dcctx_h Wv_h
+                K.gemm_batched(dcctx, sv.z, gckv[I:], M=dk, N=d, K=Md, lda=I, ldb=H * d, ldc=d, batch=H,
+                               stride_a=dk, stride_b=d, stride_c=dk * d, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)
+                dzz, dqk = self._empty(Md, H * d), self._empty(Md, H * d)
+                K.gemm_batched(dcctx, Wckv[I:], dzz, M=Md, N=d, K=dk, lda=I, ldb=d, ldc=H * d, batch=H,
+                               stride_a=dk, stride_b=dk * d, stride_c=d, trans_b=True)
+                K.cross2_bwd(st.enc_out, sv.qk, dzz, sv.z, sv.clse, dqk, xW[0, l * 2 * C2:], nd * 2 * C2 * S,
+                             xU[0, l * 2 * C2:], nd * 2 * C2 * d, N, S, H, drop_p=p, drop_seed=self._seed(st, _SITE_CATT, l, True))
+                # dq_h = dqk_h Wk_h^T ;  dWk_h += q_h^T dqk_h
+                K.gemm_batched(dqk, Wckv[:I], dqc, M=Md, N=dk, K=d, lda=H * d, ldb=d, ldc=I, batch=H,
+                               stride_a=d, stride_b=dk * d, stride_c=dk)
+                K.gemm_batched(sv.qc, dqk, gckv[:I], M=dk, N=d, K=Md, lda=I, ldb=H * d, ldc=d, batch=H,
+                               stride_a=dk, stride_b=d, stride_c=dk * d, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)
             else:
-                K.gemm(dkv, P.w(pre + "ckv"), d_enc, trans_b=True, epilogue=K.EPI_RES_DROP, aux=d_enc)
+                dkv = self._empty(M, 2 * I)
+                K.cross_attn_bwd(sv.qc, sv.kv, sv.cctx, dcctx, sv.clse, dqc, dkv, N, S, H,
+                                 drop_p=p, drop_seed=self._seed(st, _SITE_CATT, l, True))
+                self._dweight(dkv, st.enc_out, pre + "ckv")
+                if d_enc is None:
+                    d_enc = self._empty(M, d)
+                    K.gemm(dkv, P.w(pre + "ckv"), d_enc, trans_b=True)
+                else:
+                    K.gemm(dkv, P.w(pre + "ckv"), d_enc, trans_b=True, epilogue=K.EPI_RES_DROP, aux=d_enc)
+            self._dweight(dqc, sv.xn2, pre + "cq")
             K.gemm(dqc, P.w(pre + "cq"), dxn, trans_b=True)
             dg1 = self._empty(Md, d)
             dz = self._empty(Md, d) if masked_copy_needed() else None
@@ -346,6 +394,13 @@ class T5Engine:
             dg = dg0
             sv.__dict__.clear()            # release this layer's activations
         K.embedding_bwd(st.dec_ids, dg, P.grad("shared"), drop_p=p, drop_seed=self._seed(st, _SITE_DEC_EMB))
+        if st.cross2:
+            # d enc[n] = sum over layers and projected queries of ds (x) qk + dropout(p) (x) dz: one token-contraction product
+            Kc = nd * 4 * H
+            d_enc = self._empty(M, d)
+            K.gemm_batched(xW, xU, d_enc, M=S, N=d, K=Kc, lda=S, ldb=d, ldc=d, batch=N,
+                           stride_a=Kc * S, stride_b=Kc * d, stride_c=S * d, trans_a=True, trans_b=True)
+            del xW, xU
 
         # ---- encoder
         ne = dims.num_layers

@@ -85,14 +85,48 @@ def test_backward_gradients_vs_oracle(S):
         l2 = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
         worst = max(worst, l2)
         # the HIP backward also stores every activation gradient in bf16 (the oracle's autograd is
-        # fp32 over a bf16-rounded forward): 4e-2 in relative L2 per tensor.  Single elements can be
+        # fp32 over a bf16-rounded forward whose rounding points follow the reference's K/V-projection form of the
+        # cross-attention, not the re-associated form the engine takes when it can): 5e-2 in relative L2 per tensor.  Single elements can be
         # further off where a ReLU input rounds to the other side of zero in one of the two paths
         # (that unit's gradient switches on/off), so the element-wise bound is on the 99.9th percentile.
-        assert l2 < 4e-2, (k, l2)
+        # (a tensor with a handful of live entries - the decoder's relative bias sees offsets 0 and -1 only - has no
+        # averaging over elements: 8e-2 there)
+        assert l2 < (8e-2 if int((want != 0).sum()) < 16 else 5e-2), (k, l2)
         q = torch.quantile((got[k] - want).abs().flatten()[:4_000_000].float(), 0.999).item() / denom
         assert q < 0.1, (k, q, err)
         assert err < 0.5, (k, err, denom)
     assert worst > 0
+
+
+def test_cross_attention_paths_agree():
+    """The projection-free decoder cross-attention ((q Wk) . e and (p . e) Wv^T) and the explicit K/V projection path are
+    the same function: logits and every gradient agree to bf16 storage error."""
+    from pacednegatives_amd import kernels as K
+    m, _ = make_model()
+    B, S = 4, 64
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(2, TINY.vocab_size, (B, S), generator=g)
+    labels = torch.tensor([[1176, 1], [6136, 1]] * 2)
+    out = {}
+    for force in (False, True):
+        m.engine.force_kv_projection = force
+        st = m.engine.forward(ids, labels, save=True, drop_p=0.0, seed=1)
+        assert st.cross2 == (not force)
+        loss = torch.empty(B * 2, device="cuda")
+        dl = torch.empty(B * 2, TINY.vocab_size, device="cuda", dtype=torch.bfloat16)
+        K.cross_entropy(st.logits, labels.cuda().view(-1).contiguous(), loss, dl, gscale=1.0 / (B * 2))
+        m.params.g32.zero_()
+        logits = st.logits.clone()
+        m.engine.backward(st, dl)
+        torch.cuda.synchronize()
+        out[force] = (logits.cpu(), {k: v.cpu().clone() for k, v in m.params.to_hf("grad").items()})
+    m.engine.force_kv_projection = False
+    la, lb = out[False][0], out[True][0]
+    assert (la - lb).abs().max().item() < 1e-2 * lb.abs().max().item()
+    for k, want in out[True][1].items():
+        got = out[False][1][k]
+        l2 = ((got - want).norm() / (want.norm() + 1e-12)).item()
+        assert l2 < 6e-2, (k, l2)          # two bf16 paths, each within 5e-2 of the fp32 gradient
 
 
 @pytest.mark.parametrize("use_mean", [False, True])

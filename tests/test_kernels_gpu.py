@@ -391,6 +391,40 @@ def test_cross_attention(N, S, H, p):
     assert (dkv.float() - kvl.grad).abs().max().item() < 1.5e-2 * kvl.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("N,S,H,d", [(3, 16, 2, 128), (2, 101, 3, 192), (5, 256, 12, 768), (2, 64, 16, 1024)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_cross_attention_without_kv_projection(N, S, H, d, p):
+    """s = qk . e, z = dropout(softmax(s)) e over the raw encoder states, against fp32 autograd on the same bf16 inputs."""
+    C = 2 * H
+    enc = bf(rnd((N * S, d), 80, 0.5))
+    qk = bf(rnd((N * 2, H * d), 81, 0.12))
+    z = torch.empty(N * 2, H * d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(N * C, device=DEV)
+    K.cross2_fwd(enc, qk, z, lse, N, S, H, drop_p=p, drop_seed=9)
+    mask = K.dropout_mask(N * C * S, drop_p=p, drop_seed=9).view(N, C, S) if p > 0 else 1.0
+    el = enc.float().detach().clone().requires_grad_(True)
+    ql = qk.float().detach().clone().requires_grad_(True)
+    e3, q3 = el.view(N, S, d), ql.view(N, C, d)
+    s = q3 @ e3.transpose(1, 2)                                   # [N, C, S]
+    zr = (torch.softmax(s, -1) * mask) @ e3                       # [N, C, d]
+    assert (z.float().view(N, C, d) - zr).abs().max().item() < 1e-2 * zr.abs().max().item()
+    np.testing.assert_allclose(lse.view(N, C).cpu().numpy(), torch.logsumexp(s, -1).detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    dz = bf(rnd((N * 2, H * d), 82))
+    zr.backward(dz.float().view(N, C, d))
+    dqk = torch.empty_like(qk)
+    L, l = 2, 1                                                    # this call fills layer slot 1 of 2
+    W = torch.full((N, L * 2 * C, S), float("nan"), device=DEV, dtype=torch.bfloat16)
+    U = torch.full((N, L * 2 * C, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    K.cross2_bwd(enc, qk, dz, z, lse, dqk, W[0, l * 2 * C:], L * 2 * C * S, U[0, l * 2 * C:], L * 2 * C * d, N, S, H,
+                 drop_p=p, drop_seed=9)
+    assert (dqk.float() - ql.grad).abs().max().item() < 1.5e-2 * ql.grad.abs().max().item()
+    assert torch.isnan(W[:, :2 * C].float()).all() and torch.isnan(U[:, :2 * C].float()).all()      # other slots untouched
+    Wl, Ul = W[:, 2 * C:].float(), U[:, 2 * C:].float()
+    assert torch.equal(Ul[:, :C], qk.float().view(N, C, d)) and torch.equal(Ul[:, C:], dz.float().view(N, C, d))
+    de = torch.einsum("nks,nkd->nsd", Wl, Ul).reshape(N * S, d)    # the product the engine takes over all layers
+    assert (de - el.grad).abs().max().item() < 2e-2 * el.grad.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------ loss / optimiser
 def test_cross_entropy_and_lce():
     R, V = 24, 32128
