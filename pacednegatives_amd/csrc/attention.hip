@@ -704,6 +704,22 @@ __device__ __forceinline__ bf16x8 frag_rows_tr(const char* img, int ks, int lane
     return *reinterpret_cast<const bf16x8*>(img + tr_img_off(lane & 31, 2 * ks + (lane >> 5)));
 }
 
+// Stage 32 encoder rows x d features as d/64 tr images.  All global loads of the tile are issued
+// before the first LDS write, so the tile costs one memory latency, not one per image.
+template <int NF>
+__device__ __forceinline__ void stage_keys(const bf16* E, int ld, int first_row, int valid_rows, int NB, char* smem) {
+    const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+    const bool ok = first_row + r < valid_rows;
+    const bf16* src = E + (size_t)(first_row + r) * ld + c * 8;
+    bf16x8 buf[4 * NF];
+#pragma unroll
+    for (int j = 0; j < 4 * NF; ++j) buf[j] = load8(src + j * 64, ok && j < NB);
+    const int off = tr_img_off(r, c);
+#pragma unroll
+    for (int j = 0; j < 4 * NF; ++j)
+        if (j < NB) *reinterpret_cast<bf16x8*>(smem + j * 4096 + off) = buf[j];
+}
+
 struct CrossArgs {
     const bf16* enc; int ld;        // [N*S, d] rows n*S + s
     const bf16* qk;                 // [N, C, d]
@@ -729,7 +745,7 @@ __device__ __forceinline__ void reduce_tiles(float* part, int w, int lane, f32x1
 }
 
 template <int NF>
-__global__ void __launch_bounds__(256) cross2_fwd_kernel(CrossArgs a) {
+__global__ void __launch_bounds__(256, NF <= 3 ? 2 : 1) cross2_fwd_kernel(CrossArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NB = a.d >> 6;                                   // 64-wide feature slices
     float* part = reinterpret_cast<float*>(smem + NB * 4096);  // 16 KiB
@@ -757,7 +773,7 @@ __global__ void __launch_bounds__(256) cross2_fwd_kernel(CrossArgs a) {
     const int ntile = (S + 31) / 32;
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
-        for (int j = 0; j < NB; ++j) stage_tile<32>(E + j * 64, a.ld, kt * 32, S, nullptr, smem + j * 4096);
+        stage_keys<NF>(E, a.ld, kt * 32, S, NB, smem);
         __syncthreads();
         f32x16 s;
 #pragma unroll
@@ -842,7 +858,7 @@ __global__ void __launch_bounds__(256) cross2_fwd_kernel(CrossArgs a) {
 // that the caller takes over ALL decoder layers at once (one batched GEMM instead of a read-modify-write
 // of the [S, d] gradient per layer).
 template <int NF>
-__global__ void __launch_bounds__(256) cross2_bwd_kernel(CrossArgs a) {
+__global__ void __launch_bounds__(256, NF <= 1 ? 2 : 1) cross2_bwd_kernel(CrossArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NB = a.d >> 6;
     float* part = reinterpret_cast<float*>(smem + NB * 4096);  // 16 KiB
@@ -891,7 +907,7 @@ __global__ void __launch_bounds__(256) cross2_bwd_kernel(CrossArgs a) {
     const int ntile = (S + 31) / 32;
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
-        for (int j = 0; j < NB; ++j) stage_tile<32>(E + j * 64, a.ld, kt * 32, S, nullptr, smem + j * 4096);
+        stage_keys<NF>(E, a.ld, kt * 32, S, NB, smem);
         __syncthreads();
         f32x16 s, dp;
 #pragma unroll
