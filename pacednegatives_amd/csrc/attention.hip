@@ -85,6 +85,28 @@ __device__ __forceinline__ void stage_tile(const bf16* src, int ld, int first_ro
     }
 }
 
+// Register-staged [64][64] tile: thread t holds chunks t and t + 256 (row = chunk >> 3, 16-byte column = chunk & 7).
+// Loading (global -> registers) and storing (registers -> LDS images) are separate so that the loads of
+// the NEXT tile can be issued before the current tile is consumed.
+struct Tile64 { bf16x8 v[2]; };
+__device__ __forceinline__ Tile64 load_tile64(const bf16* src, int ld, int first_row, int valid_rows) {
+    Tile64 t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int g = threadIdx.x + i * 256, r = g >> 3, c = g & 7;
+        t.v[i] = load8(src + (size_t)(first_row + r) * ld + c * 8, first_row + r < valid_rows);
+    }
+    return t;
+}
+__device__ __forceinline__ void store_tile64(const Tile64& t, char* row_img, char* tr_img) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int g = threadIdx.x + i * 256, r = g >> 3, c = g & 7;
+        if (row_img) *reinterpret_cast<bf16x8*>(row_img + row_img_off(r, c)) = t.v[i];
+        if (tr_img) *reinterpret_cast<bf16x8*>(tr_img + tr_img_off(r, c)) = t.v[i];
+    }
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
     bf16x8 o;
 #pragma unroll
@@ -92,8 +114,13 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
     return o;
 }
 
+}  // namespace
+
+// (kernel templates stay outside the anonymous namespace so that their host stubs are emitted)
 // =================================================================================== forward
-// grid (ceil(S/128), H, N), 256 threads: wave w owns queries qb + 32w .. +32.
+// grid (ceil(S/128), H, N), 256 threads: wave w owns queries qb + 32w .. +32.  DROP: dropout on the
+// probabilities is compiled in (no per-element branches in the other instantiation).
+template <bool DROP>
 __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lK = smem;                 // 64 x 64 row image
@@ -119,11 +146,16 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntile = (S + 63) / 64;
+    Tile64 kreg = load_tile64(K + rowbase * a.ld, a.ld, 0, S), vreg = load_tile64(V + rowbase * a.ld, a.ld, 0, S);
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
-        stage_tile<64>(K + rowbase * a.ld, a.ld, kt * 64, S, lK, nullptr);
-        stage_tile<64>(V + rowbase * a.ld, a.ld, kt * 64, S, nullptr, lV);
+        store_tile64(kreg, lK, nullptr);
+        store_tile64(vreg, nullptr, lV);
         __syncthreads();
+        if (kt + 1 < ntile) {     // the next tile's loads fly under this tile's arithmetic
+            kreg = load_tile64(K + rowbase * a.ld, a.ld, (kt + 1) * 64, S);
+            vreg = load_tile64(V + rowbase * a.ld, a.ld, (kt + 1) * 64, S);
+        }
 
         f32x16 s[2];
         float mx = -INFINITY;
@@ -155,7 +187,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
                 float f[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.drop.thresh) {
+                if (DROP) {
                     const int key = kt * 64 + 32 * j + acc_row(r, hh);      // multiple of 4; registers r+1..r+3 hold key+1..key+3
                     if (quad_ok) drop_factor4(a.drop, dbase + key, f);
                     else {
@@ -201,6 +233,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
 
 // ====================================================================== backward: dK, dV, dBias
 // grid (ceil(S/128), H, N): wave w owns keys kb + 32w .. +32 and sweeps all queries in tiles of 32.
+template <bool DROP>
 __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lQr = smem;              // 32 x 64 row image of Q
@@ -236,29 +269,38 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
 
     float carry = 0.f;
     const int ntile = (S + 31) / 32;
+    // staged per query tile: one 16-byte chunk of Q, dO and O per thread (row = thread >> 3) and the row's LSE;
+    // the next tile's loads are issued before the current tile is consumed
+    const int sr = threadIdx.x >> 3, sc = threadIdx.x & 7;
+    bf16x8 qv = load8(Q + (rowbase + sr) * a.ld + sc * 8, sr < S);
+    bf16x8 dv = load8(DO + (rowbase + sr) * a.lddo + sc * 8, sr < S);
+    bf16x8 ov = load8(O + (rowbase + sr) * a.ldo + sc * 8, sr < S);
+    float lsev = (sr < S) ? a.lse[((size_t)n * a.H + h) * S + sr] : 0.f;
     for (int qt = 0; qt < ntile; ++qt) {
         __syncthreads();
-        {   // stage Q and dO tiles (one 16-byte chunk per thread per matrix) and delta = rowsum(dO * O)
-            const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
-            const int qrow = qt * 32 + r;
-            const bool ok = qrow < S;
-            const bf16x8 qv = load8(Q + (rowbase + qrow) * a.ld + c * 8, ok);
-            const bf16x8 dv = load8(DO + (rowbase + qrow) * a.lddo + c * 8, ok);
-            const bf16x8 ov = load8(O + (rowbase + qrow) * a.ldo + c * 8, ok);
-            *reinterpret_cast<bf16x8*>(lQr + row_img_off(r, c)) = qv;
-            *reinterpret_cast<bf16x8*>(lQt + tr_img_off(r, c)) = qv;
-            *reinterpret_cast<bf16x8*>(lDr + row_img_off(r, c)) = dv;
-            *reinterpret_cast<bf16x8*>(lDt + tr_img_off(r, c)) = dv;
+        {   // stage Q and dO tiles and delta = rowsum(dO * O)
+            *reinterpret_cast<bf16x8*>(lQr + row_img_off(sr, sc)) = qv;
+            *reinterpret_cast<bf16x8*>(lQt + tr_img_off(sr, sc)) = qv;
+            *reinterpret_cast<bf16x8*>(lDr + row_img_off(sr, sc)) = dv;
+            *reinterpret_cast<bf16x8*>(lDt + tr_img_off(sr, sc)) = dv;
             float d = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) d += bf2f(dv[j]) * bf2f(ov[j]);
             d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-            if (c == 0) {
-                ldel[r] = d;
-                llse[r] = ok ? a.lse[((size_t)n * a.H + h) * S + qrow] : 0.f;
+            if (sc == 0) {
+                ldel[sr] = d;
+                llse[sr] = lsev;
             }
         }
         __syncthreads();
+        if (qt + 1 < ntile) {
+            const int qrow = (qt + 1) * 32 + sr;
+            const bool ok = qrow < S;
+            qv = load8(Q + (rowbase + qrow) * a.ld + sc * 8, ok);
+            dv = load8(DO + (rowbase + qrow) * a.lddo + sc * 8, ok);
+            ov = load8(O + (rowbase + qrow) * a.ldo + sc * 8, ok);
+            lsev = ok ? a.lse[((size_t)n * a.H + h) * S + qrow] : 0.f;
+        }
 
         f32x16 s, dp;
 #pragma unroll
@@ -284,7 +326,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             // each to the other three.
             uint32_t w0 = 0, w1 = 0;
             const int q4 = qt * 32 + acc_row(4 * rg, hh);
-            if (a.drop.thresh && quad_ok)
+            if (DROP && quad_ok)
                 paced_drop_words(a.drop.seed, ((dnh + min(q4 + (lane & 3), S - 1)) * S + (keyc & ~3)) >> 2, w0, w1);
             uint32_t b0[4], b1[4];                     // words of queries q4 .. q4+3 (quad broadcasts of lanes 0..3)
             b0[0] = quad_bcast<0>(w0); b0[1] = quad_bcast<1>(w0); b0[2] = quad_bcast<2>(w0); b0[3] = quad_bcast<3>(w0);
@@ -297,7 +339,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
                 const bool ok = (qq < S) && (key < S);
                 const float p = ok ? __expf(s[r]) : 0.f;
                 float f = 1.f;
-                if (a.drop.thresh) {
+                if (DROP) {
                     if (quad_ok) {
                         const uint32_t wsel = (keyc & 2) ? b1[e] : b0[e];
                         const uint32_t field = (keyc & 1) ? (wsel >> 16) : (wsel & 0xffffu);
@@ -372,7 +414,8 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
 
 // ================================================================================ backward: dQ
 // grid (ceil(S/128), H, N): wave w owns queries qb + 32w .. +32 and sweeps all keys in tiles of 64.
-__global__ void __launch_bounds__(256, 3) enc_attn_bwd_dq_kernel(AttnArgs a) {
+template <bool DROP>
+__global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lKr = smem;               // 64 x 64 row image of K
     char* lKt = smem + 8192;        // tr image of K
@@ -407,11 +450,16 @@ __global__ void __launch_bounds__(256, 3) enc_attn_bwd_dq_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
 
     const int ntile = (S + 63) / 64;
+    Tile64 kreg = load_tile64(K + rowbase * a.ld, a.ld, 0, S), vreg = load_tile64(V + rowbase * a.ld, a.ld, 0, S);
     for (int kt = 0; kt < ntile; ++kt) {
         __syncthreads();
-        stage_tile<64>(K + rowbase * a.ld, a.ld, kt * 64, S, lKr, lKt);
-        stage_tile<64>(V + rowbase * a.ld, a.ld, kt * 64, S, lVr, nullptr);
+        store_tile64(kreg, lKr, lKt);
+        store_tile64(vreg, lVr, nullptr);
         __syncthreads();
+        if (kt + 1 < ntile) {
+            kreg = load_tile64(K + rowbase * a.ld, a.ld, (kt + 1) * 64, S);
+            vreg = load_tile64(V + rowbase * a.ld, a.ld, (kt + 1) * 64, S);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             f32x16 s, dp;
@@ -432,7 +480,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_bwd_dq_kernel(AttnArgs a) {
             for (int r = 0; r < 16; r += 4) {
                 const int key = kt * 64 + 32 * j + acc_row(r, hh);          // multiple of 4; registers r+1..r+3 hold key+1..key+3
                 float f[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.drop.thresh) {
+                if (DROP) {
                     if (quad_ok) drop_factor4(a.drop, dbase + key, f);
                     else {
 #pragma unroll
@@ -465,6 +513,8 @@ __global__ void __launch_bounds__(256, 3) enc_attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
 }
+
+namespace {
 
 // ======================================================= decoder self-attention over T = 2 positions
 // qkv rows (n*2 + t), [q | k | v] each H*64 wide.  One wave per (n, h), lane = head dimension.
@@ -1009,7 +1059,8 @@ extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, i
     a.out = (bf16*)ctx; a.ldo = ldo; a.lse = lse; a.bias = bias_tbl;
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const size_t smem = 16384 + (size_t)(2 * S + 64) * 4;
-    hipLaunchKernelGGL(enc_attn_fwd_kernel, dim3((S + 127) / 128, H, N), dim3(256), smem, (hipStream_t)stream, a);
+    if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_fwd_kernel<true>), dim3((S + 127) / 128, H, N), dim3(256), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((enc_attn_fwd_kernel<false>), dim3((S + 127) / 128, H, N), dim3(256), smem, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }
@@ -1030,10 +1081,12 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const dim3 grid((S + 127) / 128, H, N);
     const size_t smem1 = 16384 + (size_t)(64 + 2 * (2 * S + 160)) * 4;
-    hipLaunchKernelGGL(enc_attn_bwd_dkdv_kernel, grid, dim3(256), smem1, (hipStream_t)stream, a);
+    if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<true>), grid, dim3(256), smem1, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<false>), grid, dim3(256), smem1, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
     const size_t smem2 = 24576 + (size_t)(2 * S + 64) * 4;
-    hipLaunchKernelGGL(enc_attn_bwd_dq_kernel, grid, dim3(256), smem2, (hipStream_t)stream, a);
+    if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<true>), grid, dim3(256), smem2, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<false>), grid, dim3(256), smem2, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }
