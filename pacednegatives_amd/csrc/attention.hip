@@ -11,7 +11,8 @@
 //    vector kernels (no MFMA).
 //
 // Dropout on attention probabilities uses the counter hash of common.h with the element index
-// ((n*H + h)*Tq + q)*Tk + key, identical in forward and backward.
+// ((n*H + h)*Tq + q)*Tk4 + key, Tk4 = Tk rounded up to a multiple of 4 (so that the 4 keys a lane holds
+// in consecutive registers always share one hash evaluation), identical in forward and backward.
 #include "common.h"
 
 namespace {
@@ -180,8 +181,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
-        const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * S;
-        const bool quad_ok = (S & 3) == 0;               // registers 4g..4g+3 hold 4 consecutive keys: one hash per quad
+        const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3);   // key rows padded to quads
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -189,11 +189,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
                 float f[4] = {1.f, 1.f, 1.f, 1.f};
                 if (DROP) {
                     const int key = kt * 64 + 32 * j + acc_row(r, hh);      // multiple of 4; registers r+1..r+3 hold key+1..key+3
-                    if (quad_ok) drop_factor4(a.drop, dbase + key, f);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) f[e] = drop_factor(a.drop, dbase + key + e);
-                    }
+                    drop_factor4(a.drop, dbase + key, f);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -317,7 +313,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
         }
         f32x16 pd;   // dropped probabilities (feeds dV); s becomes dS (feeds dK)
         const uint64_t dnh = ((uint64_t)n * a.H + h) * S;
-        const bool quad_ok = (S & 3) == 0;
+        const uint64_t S4 = (uint64_t)((S + 3) & ~3);
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             // Registers 4rg..4rg+3 hold 4 consecutive queries at this lane's key; the hash covers 4
@@ -326,8 +322,8 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             // each to the other three.
             uint32_t w0 = 0, w1 = 0;
             const int q4 = qt * 32 + acc_row(4 * rg, hh);
-            if (DROP && quad_ok)
-                paced_drop_words(a.drop.seed, ((dnh + min(q4 + (lane & 3), S - 1)) * S + (keyc & ~3)) >> 2, w0, w1);
+            if (DROP)
+                paced_drop_words(a.drop.seed, ((dnh + min(q4 + (lane & 3), S - 1)) * S4 + (keyc & ~3)) >> 2, w0, w1);
             uint32_t b0[4], b1[4];                     // words of queries q4 .. q4+3 (quad broadcasts of lanes 0..3)
             b0[0] = quad_bcast<0>(w0); b0[1] = quad_bcast<1>(w0); b0[2] = quad_bcast<2>(w0); b0[3] = quad_bcast<3>(w0);
             b1[0] = quad_bcast<0>(w1); b1[1] = quad_bcast<1>(w1); b1[2] = quad_bcast<2>(w1); b1[3] = quad_bcast<3>(w1);
@@ -340,13 +336,9 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
                 const float p = ok ? __expf(s[r]) : 0.f;
                 float f = 1.f;
                 if (DROP) {
-                    if (quad_ok) {
-                        const uint32_t wsel = (keyc & 2) ? b1[e] : b0[e];
-                        const uint32_t field = (keyc & 1) ? (wsel >> 16) : (wsel & 0xffffu);
-                        f = field >= a.drop.thresh ? a.drop.scale : 0.f;
-                    } else {
-                        f = drop_factor(a.drop, (dnh + min(qq, S - 1)) * S + keyc);
-                    }
+                    const uint32_t wsel = (keyc & 2) ? b1[e] : b0[e];
+                    const uint32_t field = (keyc & 1) ? (wsel >> 16) : (wsel & 0xffffu);
+                    f = field >= a.drop.thresh ? a.drop.scale : 0.f;
                 }
                 pd[r] = p * f;
                 s[r] = p * (dp[r] * f - ldel[ql]);
@@ -474,19 +466,12 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lKr, 32 * j, ks, lane), qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lVr, 32 * j, ks, lane), dof[ks], dp, 0, 0, 0);
             }
-            const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * S;
-            const bool quad_ok = (S & 3) == 0;
+            const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3);
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
                 const int key = kt * 64 + 32 * j + acc_row(r, hh);          // multiple of 4; registers r+1..r+3 hold key+1..key+3
                 float f[4] = {1.f, 1.f, 1.f, 1.f};
-                if (DROP) {
-                    if (quad_ok) drop_factor4(a.drop, dbase + key, f);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) f[e] = drop_factor(a.drop, dbase + key + e);
-                    }
-                }
+                if (DROP) drop_factor4(a.drop, dbase + key, f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float pe = (key + e < S) ? __expf(s[r + e]) : 0.f;
@@ -817,8 +802,7 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 2 : 1) cross2_fwd_kernel(CrossA
 #pragma unroll
         for (int r = 0; r < 16; ++r) { zacc[f][0][r] = 0.f; zacc[f][1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    const uint64_t dbase = ((uint64_t)n * C + min(c, C - 1)) * S;
-    const bool quad_ok = (S & 3) == 0;
+    const uint64_t dbase = ((uint64_t)n * C + min(c, C - 1)) * (uint64_t)((S + 3) & ~3);     // key rows padded to quads
 
     const int ntile = (S + 31) / 32;
     for (int kt = 0; kt < ntile; ++kt) {
@@ -851,11 +835,7 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 2 : 1) cross2_fwd_kernel(CrossA
             float fct[4] = {1.f, 1.f, 1.f, 1.f};
             if (a.drop.thresh) {
                 const int key = kt * 32 + acc_row(r, hh);
-                if (quad_ok) drop_factor4(a.drop, dbase + key, fct);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fct[e] = drop_factor(a.drop, dbase + min(key + e, S - 1));
-                }
+                drop_factor4(a.drop, dbase + key, fct);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -950,7 +930,7 @@ __global__ void __launch_bounds__(256, NF <= 1 ? 2 : 1) cross2_bwd_kernel(CrossA
     for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { qacc[f][0][r] = 0.f; qacc[f][1][r] = 0.f; }
-    const uint64_t dbase = ((uint64_t)n * C + cc) * S;
+    const uint64_t dbase = ((uint64_t)n * C + cc) * (uint64_t)((S + 3) & ~3);
     const bool quad_ok = (S & 3) == 0;
     bf16* wrow = a.wslot + (size_t)n * a.wstride + (size_t)cc * S;
 
@@ -982,11 +962,7 @@ __global__ void __launch_bounds__(256, NF <= 1 ? 2 : 1) cross2_bwd_kernel(CrossA
             const int key = kt * 32 + acc_row(r, hh);
             float fct[4] = {1.f, 1.f, 1.f, 1.f};
             if (a.drop.thresh) {
-                if (quad_ok) drop_factor4(a.drop, dbase + key, fct);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fct[e] = drop_factor(a.drop, dbase + min(key + e, S - 1));
-                }
+                drop_factor4(a.drop, dbase + key, fct);
             }
             bf16x4 dsv, pdv;
 #pragma unroll

@@ -297,7 +297,8 @@ def test_enc_attention_fwd_bwd(N, S, H, p):
     K.enc_attn_fwd(q, k, v, ctx, lse, tbl, N, S, H, drop_p=p, drop_seed=seed)
     mask = None
     if p > 0:
-        mask = K.dropout_mask(N * H * S * S, drop_p=p, drop_seed=seed).view(N, H, S, S)
+        S4 = (S + 3) // 4 * 4          # the kernels count keys in rows padded to a multiple of 4
+        mask = K.dropout_mask(N * H * S * S4, drop_p=p, drop_seed=seed).view(N, H, S, S4)[..., :S]
     ql, kl, vl = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
     tl = tbl.clone().requires_grad_(True)
     o_ref, lse_ref = _ref_attention(ql, kl, vl, _dense_bias(tl, S), N, S, H, mask)
@@ -401,7 +402,8 @@ def test_cross_attention_without_kv_projection(N, S, H, d, p):
     z = torch.empty(N * 2, H * d, device=DEV, dtype=torch.bfloat16)
     lse = torch.empty(N * C, device=DEV)
     K.cross2_fwd(enc, qk, z, lse, N, S, H, drop_p=p, drop_seed=9)
-    mask = K.dropout_mask(N * C * S, drop_p=p, drop_seed=9).view(N, C, S) if p > 0 else 1.0
+    S4 = (S + 3) // 4 * 4
+    mask = K.dropout_mask(N * C * S4, drop_p=p, drop_seed=9).view(N, C, S4)[..., :S] if p > 0 else 1.0
     el = enc.float().detach().clone().requires_grad_(True)
     ql = qk.float().detach().clone().requires_grad_(True)
     e3, q3 = el.view(N, S, d), ql.view(N, C, d)
