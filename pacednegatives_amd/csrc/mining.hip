@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int CH_FIRST = 4096;
-constexpr int CH_MAX = 16384;
+constexpr int CH_MAX = 131072;
 constexpr int K_MAX = 4096;
 
 __host__ __device__ inline int cap_for(int k) { return 2 * k + CH_MAX; }
