@@ -195,13 +195,16 @@ __global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restr
 // One workgroup per logits row (fp32, V columns).  loss = logsumexp(row) - row[label]; rows whose
 // label equals ignore_index give loss 0 and a zero gradient.  dlogits (optional, bf16) =
 // (softmax - onehot) * gscale.
+// exp(a - b) for a <= b where both may be -inf (an empty partial): the empty side contributes nothing
+__device__ __forceinline__ float exp_diff(float a, float b) { return a == b ? 1.f : __expf(a - b); }
+
 __device__ __forceinline__ void block_reduce_max_sum(float& m, float& s, float* sh) {
-    // combine (max, sum-exp) pairs: wave level then across the 4 waves
+    // combine (max, sum-exp) pairs: wave level then across the 4 waves; threads without elements hold (-inf, 0)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
         const float mn = fmaxf(m, m2);
-        s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+        s = s * exp_diff(m, mn) + s2 * exp_diff(m2, mn);
         m = mn;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -212,7 +215,7 @@ __device__ __forceinline__ void block_reduce_max_sum(float& m, float& s, float* 
     for (int i = 1; i < 4; ++i) {
         const float m2 = sh[i * 2], s2 = sh[i * 2 + 1];
         const float mn = fmaxf(M, m2);
-        S = S * __expf(M - mn) + s2 * __expf(m2 - mn);
+        S = S * exp_diff(M, mn) + s2 * exp_diff(m2, mn);
         M = mn;
     }
     m = M; s = S;

@@ -277,8 +277,9 @@ class T5Engine:
         rstd_df = torch.empty(Md, dtype=F32, device=self.device)
         K.rmsnorm_fwd(g, P.w("dec.final_ln"), y, rstd_df, eps=dims.eps, out_scale=d ** -0.5,
                       drop_p=p, drop_seed=self._seed(st, _SITE_DEC_FINAL))
+        st.y = y
         if save:
-            st.g_last, st.rstd_df, st.y = g, rstd_df, y
+            st.g_last, st.rstd_df = g, rstd_df
         if want_logits:
             st.logits = torch.empty(Md, dims.vocab_size, dtype=F32, device=self.device)
             K.gemm(y, P.w("shared"), st.logits, epilogue=K.EPI_F32)
@@ -291,7 +292,7 @@ class T5Engine:
         """Accumulate parameter gradients of one forward call into ``params.g32`` given d loss / d logits
         (bf16 [N*2, V]).  The forward must have been run with ``save=True``."""
         dims, P = self.dims, self.params
-        if not st.enc_layers or st.y is None:
+        if not st.enc_layers or st.g_last is None:
             raise RuntimeError("backward needs a forward state produced with save=True")
         N, S, p = st.N, st.S, st.p
         d, I, ff, H = dims.d_model, dims.inner, dims.d_ff, dims.num_heads

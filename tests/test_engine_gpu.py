@@ -46,6 +46,28 @@ def test_forward_logits_vs_hf_fixture_and_oracle(golden_dir, ci):
     np.testing.assert_allclose(ce(got).numpy(), ce(hf).numpy(), rtol=1e-2)
 
 
+@pytest.mark.parametrize("ci", [0, 1])
+def test_monot5_score_vs_hf_fixture_and_oracle(golden_dir, ci):
+    """log_softmax(logits[:, 0, (true, false)])[:, 0] (reference distill/wrapper.py:34-38) from the two-row head."""
+    from pacednegatives_amd.scorer import MonoT5Model
+    g = np.load(os.path.join(golden_dir, "t5_forward.npz"))
+    ids, labels = torch.from_numpy(g[f"t5_ids{ci}"]), torch.from_numpy(g[f"t5_labels{ci}"])
+    m, P = make_model()
+    m.eval()
+    got = MonoT5Model(m)({"input_ids": ids})
+    assert got.shape == (ids.shape[0],) and got.dtype == torch.float32 and not got.is_cuda
+    ref = lambda lg: torch.log_softmax(lg[:, 0, [1176, 6136]].float(), dim=1)[:, 0]  # noqa: E731
+    hf = ref(torch.from_numpy(g[f"t5_logits{ci}"]))
+    emu = ref(t5_forward(P, RTINY, ids, labels, emulate_bf16=True))
+    # a difference of two logits: twice the logit bound of the forward test (6e-3 x scale, scale ~ 1) against the
+    # oracle with bf16 rounding at the same points, 3e-2 against the Hugging Face fp32 logits (bf16 storage error)
+    assert (got - emu).abs().max().item() < 1.2e-2
+    assert (got - hf).abs().max().item() < 3e-2
+    # the generated labels do not matter at position 0: same scores as the full-head path with other labels
+    full = m(input_ids=ids, labels=torch.tensor([[6136, 1]] * ids.shape[0])).logits.cpu()
+    assert (got - ref(full)).abs().max().item() < 2e-3
+
+
 def test_forward_is_batch_invariant():
     m, _ = make_model()
     m.eval()

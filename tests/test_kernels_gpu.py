@@ -452,6 +452,16 @@ def test_cross_entropy_and_lce():
     assert torch.allclose(ce, pce + nce.view(-1, n).mean(1))
 
 
+def test_cross_entropy_narrow_rows():
+    """Fewer columns than threads: partial (max, sum) pairs of idle threads must not poison the reduction."""
+    logits = rnd((5, 8), 55, 3.0).to(DEV)
+    labels = torch.tensor([0, 3, 1, 2, 0], device=DEV)
+    loss = torch.empty(5, device=DEV)
+    K.cross_entropy(logits[:, :4], labels, loss)
+    want = torch.nn.functional.cross_entropy(logits[:, :4], labels, reduction="none")
+    np.testing.assert_allclose(loss.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_lce_weights_known_answer():
     loss = torch.tensor([0.1, 0.5, 2.0, 0.3], device=DEV)
     eta = torch.tensor([0.4], device=DEV)
