@@ -30,7 +30,7 @@ for n in sorted(set(fetch) | set(write)):
     rd = 2.0 * fetch[n][1] * 1024 / launches
     wr = write[n][1] * 1024 / launches
     out[n] = {"launches": launches, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-gemm = [v for k, v in out.items() if "gemm_bf16_kernel" in k]
+gemm = [v for k, v in out.items() if "gemm_bf16_kernel" in k or "gemm_phased_kernel" in k]     # every paced_gemm_bf16 launch
 tot_l = sum(v["launches"] for v in gemm)
 summary = {"per_kernel": out,
            "gemm_bf16_kernel": {"launches": tot_l,
