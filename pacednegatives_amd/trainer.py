@@ -35,15 +35,20 @@ class JSONLLogger:
 
 
 def init_distributed():
-    """Join the process group described by the torchrun environment; returns (rank, world, local_rank)."""
+    """Join the process group described by the torchrun environment; returns (rank, world, device index).
+
+    With fewer visible GPUs than local ranks (a rehearsal of the multi-rank path on a one-GPU machine) the ranks
+    share devices round-robin; RCCL refuses two ranks on one device, so such a run needs PACED_DIST_BACKEND=gloo."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        local %= max(1, torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("PACED_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
