@@ -120,6 +120,42 @@ def test_backward_gradients_vs_oracle(S):
     assert worst > 0
 
 
+@pytest.mark.parametrize("d,H,ff", [(512, 8, 1024), (768, 12, 1536)])
+def test_forward_backward_at_real_widths(d, H, ff):
+    """The t5-small / t5-base widths (2 layers, reduced vocabulary and d_ff to keep the CPU oracle quick): exercises the
+    kernel instantiations the benchmark uses (12 heads, 3 feature slices per wave in the cross-attention, ...)."""
+    from pacednegatives_amd import kernels as K
+    from pacednegatives_amd.config import T5Dims
+    from pacednegatives_amd.model import T5ForConditionalGenerationHIP
+    dims = T5Dims(6400, d, 64, H, ff, 2, 2)
+    rd = RefDims(6400, d, 64, H, ff, 2, 2)
+    m = T5ForConditionalGenerationHIP(dims, device="cuda", init=False)
+    P = init_params(rd, 3)
+    m.params.load_hf(P)
+    B, S = 3, 48
+    g = torch.Generator().manual_seed(13)
+    ids = torch.randint(2, 6400, (B, S), generator=g)
+    labels = torch.tensor([[1176, 1], [6136, 1], [6136, 1]])
+    st = m.engine.forward(ids, labels, save=True, drop_p=0.0, seed=1)
+    assert st.cross2
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lg = t5_forward(leaves, rd, ids, labels, emulate_bf16=True)
+    scale = lg.abs().max().item()
+    assert (st.logits.cpu().view_as(lg) - lg.detach()).abs().max().item() < 6e-3 * scale
+    loss = torch.empty(B * 2, device="cuda")
+    dl = torch.empty(B * 2, 6400, device="cuda", dtype=torch.bfloat16)
+    K.cross_entropy(st.logits, labels.cuda().view(-1).contiguous(), loss, dl, gscale=1.0 / (B * 2))
+    m.params.g32.zero_()
+    m.engine.backward(st, dl)
+    torch.cuda.synchronize()
+    got = {k: v.cpu() for k, v in m.params.to_hf("grad").items()}
+    torch.nn.functional.cross_entropy(lg.view(-1, lg.shape[-1]), labels.view(-1), reduction="mean").backward()
+    for k, v in leaves.items():
+        want = v.grad if v.grad is not None else torch.zeros_like(v)
+        l2 = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
+        assert l2 < (8e-2 if int((want != 0).sum()) < 64 else 5e-2), (k, l2)
+
+
 def test_cross_attention_paths_agree():
     """The projection-free decoder cross-attention ((q Wk) . e and (p . e) Wv^T) and the explicit K/V projection path are
     the same function: logits and every gradient agree to bf16 storage error."""
