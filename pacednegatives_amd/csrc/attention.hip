@@ -170,12 +170,13 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lK, 32 * j, ks, lane), qf[ks], s[j], 0, 0, 0);
+            if (kt * 64 + 64 > S) {          // only the last, ragged tile has keys to mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + 32 * j + acc_row(r, hh);
-                if (key >= S) s[j][r] = -INFINITY;
-                mx = fmaxf(mx, s[j][r]);
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 64 + 32 * j + acc_row(r, hh) >= S) s[j][r] = -INFINITY;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
                 float f[4] = {1.f, 1.f, 1.f, 1.f};
                 if (DROP) {
                     const int key = kt * 64 + 32 * j + acc_row(r, hh);      // multiple of 4; registers r+1..r+3 hold key+1..key+3
-                    drop_factor4(a.drop, dbase + key, f);
+                    drop_factor4_on(a.drop, dbase + key, f);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -467,14 +468,15 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lVr, 32 * j, ks, lane), dof[ks], dp, 0, 0, 0);
             }
             const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3);
+            const bool full = kt * 64 + 64 <= S;          // no key of this tile is out of range (uniform)
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
                 const int key = kt * 64 + 32 * j + acc_row(r, hh);          // multiple of 4; registers r+1..r+3 hold key+1..key+3
                 float f[4] = {1.f, 1.f, 1.f, 1.f};
-                if (DROP) drop_factor4(a.drop, dbase + key, f);
+                if (DROP) drop_factor4_on(a.drop, dbase + key, f);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = (key + e < S) ? __expf(s[r + e]) : 0.f;
+                    const float pe = (full || key + e < S) ? __expf(s[r + e]) : 0.f;
                     s[r + e] = pe * (dp[r + e] * f[e] - delta);
                 }
             }

@@ -94,6 +94,15 @@ __device__ __forceinline__ void drop_factor4(const DropCfg& d, uint64_t idx4, fl
     f[2] = (h1 & 0xffffu) >= d.thresh ? d.scale : 0.f;
     f[3] = (h1 >> 16) >= d.thresh ? d.scale : 0.f;
 }
+// same with dropout known to be on (no uniform branch per call)
+__device__ __forceinline__ void drop_factor4_on(const DropCfg& d, uint64_t idx4, float (&f)[4]) {
+    uint32_t h0, h1;
+    paced_drop_words(d.seed, idx4 >> 2, h0, h1);
+    f[0] = (h0 & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    f[1] = (h0 >> 16) >= d.thresh ? d.scale : 0.f;
+    f[2] = (h1 & 0xffffu) >= d.thresh ? d.scale : 0.f;
+    f[3] = (h1 >> 16) >= d.thresh ? d.scale : 0.f;
+}
 // factors of 8 consecutive elements starting at a multiple of 4
 __device__ __forceinline__ void drop_factor8(const DropCfg& d, uint64_t idx4, float (&f)[8]) {
     float a[4], b[4];
