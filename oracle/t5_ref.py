@@ -188,8 +188,12 @@ def _lin(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 
 def t5_forward(params: Dict[str, torch.Tensor], dims: T5Dims, input_ids: torch.Tensor, labels: torch.Tensor,
-               emulate_bf16: bool = False, return_internals: bool = False):
-    """Logits [N, T, V] (fp32) of ``T5ForConditionalGeneration(input_ids, labels)`` with dropout 0.
+               emulate_bf16: bool = False, return_internals: bool = False, drop=None):
+    """Logits [N, T, V] (fp32) of ``T5ForConditionalGeneration(input_ids, labels)`` with dropout 0, or with
+    caller-supplied dropout masks: ``drop(site, layer, dec, shape)`` returns the factor tensor (0 or 1/(1-p)) of
+    that shape for the dropout sites of HF modeling_t5.py - "emb" (:725), "final" (:745), "att" (:168, on the
+    probabilities, shape [N,H,T,S]), "att_out" (:400), "ff_act" (:86), "ff_out" (:140), "catt" / "catt_out"
+    (:168 / :431 of the cross-attention) - so that a test can replay the masks another implementation used.
 
     Structure: HF:663-750 (stack), HF:392-400/304-367 (self-attention sub-layer), HF:138-140/84-93
     (feed-forward sub-layer), HF:459-498 (decoder block), HF:618-637 (shift right), HF:1044-1047
@@ -200,8 +204,15 @@ def t5_forward(params: Dict[str, torch.Tensor], dims: T5Dims, input_ids: torch.T
     H, dk, eps = dims.num_heads, dims.d_kv, dims.eps
     internals = {}
 
+    def dm(site, layer, dec, x):            # dropout on a hidden-state tensor
+        return x if drop is None else x * drop(site, layer, dec, tuple(x.shape))
+
+    def pm(site, layer, dec, n, t, sl):     # dropout factors for attention probabilities
+        return None if drop is None else drop(site, layer, dec, (n, H, t, sl))
+    N = input_ids.shape[0]
+
     # ---- encoder
-    h = r(P["shared.weight"][input_ids])                       # [N,S,d]
+    h = r(dm("emb", 0, False, P["shared.weight"][input_ids]))  # [N,S,d]
     S = input_ids.shape[1]
     enc_bias = position_bias(P["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], S, S, True, dims)
     for l in range(dims.num_layers):
@@ -210,14 +221,14 @@ def t5_forward(params: Dict[str, torch.Tensor], dims: T5Dims, input_ids: torch.T
         q = r(_lin(xn, P[p + "0.SelfAttention.q.weight"]))
         k = r(_lin(xn, P[p + "0.SelfAttention.k.weight"]))
         v = r(_lin(xn, P[p + "0.SelfAttention.v.weight"]))
-        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), enc_bias, False, r))
-        h = r(h + _lin(ctx, P[p + "0.SelfAttention.o.weight"]))
+        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), enc_bias, False, r, pm("att", l, False, N, S, S)))
+        h = r(h + dm("att_out", l, False, _lin(ctx, P[p + "0.SelfAttention.o.weight"])))
         xn = r(rms_norm(h, P[p + "1.layer_norm.weight"], eps))
-        a = r(torch.relu(_lin(xn, P[p + "1.DenseReluDense.wi.weight"])))
-        h = r(h + _lin(a, P[p + "1.DenseReluDense.wo.weight"]))
+        a = r(dm("ff_act", l, False, torch.relu(_lin(xn, P[p + "1.DenseReluDense.wi.weight"]))))
+        h = r(h + dm("ff_out", l, False, _lin(a, P[p + "1.DenseReluDense.wo.weight"])))
         if return_internals:
             internals[f"enc{l}"] = h
-    enc = r(rms_norm(h, P["encoder.final_layer_norm.weight"], eps))
+    enc = r(dm("final", 0, False, rms_norm(h, P["encoder.final_layer_norm.weight"], eps)))
     if return_internals:
         internals["enc_out"] = enc
 
@@ -226,7 +237,7 @@ def t5_forward(params: Dict[str, torch.Tensor], dims: T5Dims, input_ids: torch.T
     dec_ids[:, 1:] = labels[:, :-1]
     dec_ids = dec_ids.masked_fill(dec_ids == -100, 0)
     T = dec_ids.shape[1]
-    h = r(P["shared.weight"][dec_ids])
+    h = r(dm("emb", 0, True, P["shared.weight"][dec_ids]))
     dec_bias = position_bias(P["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], T, T, False, dims)
     for l in range(dims.num_decoder_layers):
         p = f"decoder.block.{l}.layer."
@@ -234,20 +245,20 @@ def t5_forward(params: Dict[str, torch.Tensor], dims: T5Dims, input_ids: torch.T
         q = r(_lin(xn, P[p + "0.SelfAttention.q.weight"]))
         k = r(_lin(xn, P[p + "0.SelfAttention.k.weight"]))
         v = r(_lin(xn, P[p + "0.SelfAttention.v.weight"]))
-        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), dec_bias, True, r))
-        h = r(h + _lin(ctx, P[p + "0.SelfAttention.o.weight"]))
+        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), dec_bias, True, r, pm("att", l, True, N, T, T)))
+        h = r(h + dm("att_out", l, True, _lin(ctx, P[p + "0.SelfAttention.o.weight"])))
         xn = r(rms_norm(h, P[p + "1.layer_norm.weight"], eps))
         q = r(_lin(xn, P[p + "1.EncDecAttention.q.weight"]))
         k = r(_lin(enc, P[p + "1.EncDecAttention.k.weight"]))
         v = r(_lin(enc, P[p + "1.EncDecAttention.v.weight"]))
-        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), None, False, r))
-        h = r(h + _lin(ctx, P[p + "1.EncDecAttention.o.weight"]))
+        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), None, False, r, pm("catt", l, True, N, T, S)))
+        h = r(h + dm("catt_out", l, True, _lin(ctx, P[p + "1.EncDecAttention.o.weight"])))
         xn = r(rms_norm(h, P[p + "2.layer_norm.weight"], eps))
-        a = r(torch.relu(_lin(xn, P[p + "2.DenseReluDense.wi.weight"])))
-        h = r(h + _lin(a, P[p + "2.DenseReluDense.wo.weight"]))
+        a = r(dm("ff_act", l, True, torch.relu(_lin(xn, P[p + "2.DenseReluDense.wi.weight"]))))
+        h = r(h + dm("ff_out", l, True, _lin(a, P[p + "2.DenseReluDense.wo.weight"])))
         if return_internals:
             internals[f"dec{l}"] = h
-    y = rms_norm(h, P["decoder.final_layer_norm.weight"], eps)
+    y = dm("final", 0, True, rms_norm(h, P["decoder.final_layer_norm.weight"], eps))
     y = r(y * (dims.d_model ** -0.5))                          # HF:1044-1045 (tied embeddings)
     logits = _lin(y, P["shared.weight"])                       # HF:1047
     if return_internals:

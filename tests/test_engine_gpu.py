@@ -3,6 +3,7 @@ fixtures recorded from Hugging Face T5 / the reference.  Tolerances: the HIP pat
 in bf16 (8 significant bits); against the oracle run with bf16 rounding at the same points the
 difference is accumulation order only (1e-3-class); against the fp32 fixtures it is the bf16 storage
 error itself (a few 1e-2 of the logit scale)."""
+import math
 import os
 import warnings
 
@@ -154,6 +155,63 @@ def test_forward_backward_at_real_widths(d, H, ff):
         want = v.grad if v.grad is not None else torch.zeros_like(v)
         l2 = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
         assert l2 < (8e-2 if int((want != 0).sum()) < 64 else 5e-2), (k, l2)
+
+
+def test_dropout_masks_replayed_in_the_oracle():
+    """Dropout ON: the engine never stores a mask, forward and backward kernels recompute it from (seed, site, index).
+    Rebuild every site's mask from the same seeds with the library's mask function, replay them in the oracle and
+    compare logits and all gradients: pins the seed wiring and index layout of all ten dropout sites of both stacks."""
+    from pacednegatives_amd import kernels as K
+    from pacednegatives_amd import t5_engine as E
+    m, P = make_model()
+    B, S, p = 3, 32, 0.1
+    H = TINY.num_heads
+    g = torch.Generator().manual_seed(21)
+    ids = torch.randint(2, TINY.vocab_size, (B, S), generator=g)
+    labels = torch.tensor([[6136, 1], [1176, 1], [6136, 1]])
+    st = m.engine.forward(ids, labels, save=True, drop_p=p, seed=77)
+    assert st.cross2
+    site_id = {"emb": (E._SITE_EMB, E._SITE_DEC_EMB), "final": (E._SITE_ENC_FINAL, E._SITE_DEC_FINAL), "att": E._SITE_ATT,
+               "att_out": E._SITE_ATT_OUT, "ff_act": E._SITE_FF_ACT, "ff_out": E._SITE_FF_OUT, "catt": E._SITE_CATT,
+               "catt_out": E._SITE_CATT_OUT}
+
+    def drop(site, layer, dec, shape):
+        sid = site_id[site]
+        if isinstance(sid, tuple):             # stack-level sites have their own ids per stack and no decoder offset
+            sid, dec = sid[1 if dec else 0], False
+        seed = m.engine._seed(st, sid, layer, dec)
+        mk = lambda n: K.dropout_mask(n, drop_p=p, drop_seed=seed).cpu()  # noqa: E731
+        if site == "att" and not dec:              # [N,H,S,S4] with key rows padded to a multiple of 4
+            n, h, t, sl = shape
+            s4 = (sl + 3) // 4 * 4
+            return mk(n * h * t * s4).view(n, h, t, s4)[..., :sl]
+        if site == "att":                          # decoder self-attention: [N,H,2,2]
+            return mk(math.prod(shape)).view(shape)
+        if site == "catt":                         # projected queries c = t*H + h: [N, 2, H, S4] -> [N,H,2,S]
+            n, h, t, sl = shape
+            s4 = (sl + 3) // 4 * 4
+            return mk(n * t * h * s4).view(n, t, h, s4)[..., :sl].permute(0, 2, 1, 3)
+        return mk(math.prod(shape)).view(shape)    # hidden states: token row x feature
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lg = t5_forward(leaves, RTINY, ids, labels, emulate_bf16=True, drop=drop)
+    scale = lg.abs().max().item()
+    assert (st.logits.cpu().view_as(lg) - lg.detach()).abs().max().item() < 6e-3 * scale
+    # with the masks of another seed the logits differ far more than that: the comparison is not vacuous
+    st2 = m.engine.forward(ids, labels, save=False, drop_p=p, seed=78)
+    assert (st2.logits.cpu().view_as(lg) - lg.detach()).abs().max().item() > 5e-2 * scale
+    loss = torch.empty(B * 2, device="cuda")
+    dl = torch.empty(B * 2, TINY.vocab_size, device="cuda", dtype=torch.bfloat16)
+    K.cross_entropy(st.logits, labels.cuda().view(-1).contiguous(), loss, dl, gscale=1.0 / (B * 2))
+    m.params.g32.zero_()
+    m.engine.backward(st, dl)
+    torch.cuda.synchronize()
+    got = {k: v.cpu() for k, v in m.params.to_hf("grad").items()}
+    torch.nn.functional.cross_entropy(lg.view(-1, lg.shape[-1]), labels.view(-1), reduction="mean").backward()
+    for k, v in leaves.items():
+        want = v.grad if v.grad is not None else torch.zeros_like(v)
+        l2 = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
+        assert l2 < (8e-2 if int((want != 0).sum()) < 16 else 5e-2), (k, l2)
 
 
 def test_cross_attention_paths_agree():
