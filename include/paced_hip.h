@@ -43,10 +43,13 @@ const char* paced_last_error(void);
  * epilogue:
  *   0  C(bf16) = acc
  *   1  C(bf16) = aux + dropout(acc)                  residual add, HF:400-401, HF:140
- *   2  C(bf16) = dropout(relu(acc))                  HF:85-86
+ *   2  C(bf16) = dropout(relu(acc))                  HF:85-86; when aux is not NULL it is an output here: a byte
+ *                                                    matrix, ldaux BYTES per row, bit (n%8) of byte n/8 of row m = (C[m][n] > 0)
  *   3  C(bf16) = aux > 0 ? acc * mask_scale : 0      backward of (2) given its saved output
  *   4  C(f32)  = acc
  *   5  C(f32) += acc   (atomic; required when splits > 1)
+ *   6  C(bf16) = bit(aux, m, n) ? acc * mask_scale : 0   backward of (2) given the byte matrix it wrote (N % 8 == 0,
+ *                                                    ldaux >= N/8 bytes); reads 1/16 of what (3) reads
  * Requirements: K % 64 == 0 for a non-transposed operand; N % 4 == 0; lda, ldb % 8 == 0;
  * 16-byte aligned bases.  M, N and a transposed contraction length may be ragged. */
 int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,

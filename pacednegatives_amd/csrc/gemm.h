@@ -5,13 +5,14 @@
 enum Epi : int {
     EPI_BF16 = 0,        // C = acc
     EPI_RES_DROP = 1,    // C = aux + dropout(acc)
-    EPI_RELU_DROP = 2,   // C = dropout(relu(acc))
+    EPI_RELU_DROP = 2,   // C = dropout(relu(acc)); if aux: bit (m, n) of the byte matrix aux = (C > 0)
     EPI_MASK = 3,        // C = acc * (aux > 0 ? mask_scale : 0)
     EPI_F32 = 4,         // C(f32) = acc
     EPI_ATOMIC_F32 = 5,  // C(f32) += acc   (atomic, split-K allowed)
+    EPI_MASK_BITS = 6,   // C = acc * (bit (m, n) of the byte matrix aux ? mask_scale : 0)
     EPI_COUNT,           // ---- epilogues below are internal to the pool scorer (mining.hip)
-    EPI_TOPK_DENSE = 6,  // cand[n][m] = key(acc, row_base + m)
-    EPI_TOPK_FILTER = 7  // if acc >= thr[n]: cand[n][cnt[n]++] = key(acc, row_base + m)
+    EPI_TOPK_DENSE = 7,  // cand[n][m] = key(acc, row_base + m)
+    EPI_TOPK_FILTER = 8  // if acc >= thr[n]: cand[n][cnt[n]++] = key(acc, row_base + m)
 };
 
 struct GemmParams {

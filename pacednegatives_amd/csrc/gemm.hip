@@ -130,6 +130,12 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, void* Cb, int m,
             if (EPI == EPI_RES_DROP) v[r] = bf2f(x[r]) + v[r] * f[r];
             else v[r] = bf2f(x[r]) > 0.f ? v[r] * p.mask_scale : 0.f;
         }
+    } else if (EPI == EPI_MASK_BITS) {
+        // one bit per element, 8 columns per byte, ldaux bytes per row; this quad is the low or high nibble
+        const unsigned int byte = reinterpret_cast<const unsigned char*>(p.aux)[(size_t)m * p.ldaux + (n >> 3)];
+        const unsigned int nib = byte >> (n & 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] * p.mask_scale : 0.f;
     } else if (EPI == EPI_RELU_DROP) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f) * f[r];
@@ -137,6 +143,16 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, void* Cb, int m,
     bf16x4 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+    if (EPI == EPI_RELU_DROP && p.aux) {
+        // sign bits of the 8 columns n&~7 .. +7 of row m: this lane's nibble and that of the lane 16 further on
+        // (same row, next quad); N % 8 == 0, so the partner of an in-range even quad is in range too
+        unsigned int nib = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nib |= (bf2f(o[r]) > 0.f ? 1u : 0u) << r;
+        const unsigned int other = (unsigned int)__shfl_xor((int)nib, 16, 64);
+        if ((n & 4) == 0)
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (n >> 3)] = (unsigned char)(nib | (other << 4));
+    }
     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(Cb) + ci) = o;
 }
 
@@ -458,6 +474,16 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int
     const int rr = lane >> 3, c = lane & 7;
     const int ncol = n0 + wc * 64 + c * 8;
     const bool col_ok = ncol < p.N;                   // N is a multiple of 8 on this path
+    unsigned int mbits[8][2];
+    if (EPI == EPI_MASK_BITS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
+                mbits[i][q] = (m < p.M && col_ok) ? reinterpret_cast<const unsigned char*>(p.aux)[(size_t)m * p.ldaux + (ncol >> 3)] : 0u;
+            }
+    }
     bf16x8 aux[8][2];
     if (EPI == EPI_RES_DROP || EPI == EPI_MASK) {
 #pragma unroll
@@ -489,7 +515,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (EPI == EPI_MASK) {
+            if (EPI == EPI_MASK || EPI == EPI_MASK_BITS) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= p.mask_scale;
             }
@@ -514,8 +540,17 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int
             } else if (EPI == EPI_MASK) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = bf2f(aux[i][q][e]) > 0.f ? t[e] : (bf16)0.f;
+            } else if (EPI == EPI_MASK_BITS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = ((mbits[i][q] >> e) & 1u) ? t[e] : (bf16)0.f;
             }
             const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
+            if (EPI == EPI_RELU_DROP && p.aux && m < p.M && col_ok) {
+                unsigned int byte = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) byte |= (bf2f(t[e]) > 0.f ? 1u : 0u) << e;
+                const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (ncol >> 3)] = (unsigned char)byte;
+            }
             if (m < p.M && col_ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
         }
     }
@@ -636,7 +671,7 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
             quadrant_mfma<NATURAL>(fa, fb0, acc, 1, 0);
             PACED_PINNED_BARRIER();
         }
-        if (EPI == EPI_BF16 || EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP || EPI == EPI_MASK) {
+        if (EPI == EPI_BF16 || EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP || EPI == EPI_MASK || EPI == EPI_MASK_BITS) {
             char* s1 = sw + ring_wrap(base + 8) * HALF;      // the finished K step's B half 1 and A half 1 slots
             char* s2 = sw + ring_wrap(base + 9) * HALF;
             epilogue_rows<EPI>(p, batch_c<EPI>(p, bz), m0, n0, wr, wc, lane, acc, s1, s1 + 8192, s2, s2 + 8192);
@@ -743,6 +778,7 @@ int dispatch_epi(const GemmParams& p, int epi, int splits, hipStream_t s) {
         case EPI_RES_DROP: return launch<TA, TB, EPI_RES_DROP>(p, splits, s);
         case EPI_RELU_DROP: return launch<TA, TB, EPI_RELU_DROP>(p, splits, s);
         case EPI_MASK: return launch<TA, TB, EPI_MASK>(p, splits, s);
+        case EPI_MASK_BITS: return launch<TA, TB, EPI_MASK_BITS>(p, splits, s);
         case EPI_F32: return launch<TA, TB, EPI_F32>(p, splits, s);
         case EPI_ATOMIC_F32: return launch<TA, TB, EPI_ATOMIC_F32>(p, splits, s);
         case EPI_TOPK_DENSE: if (!TA && !TB) return launch<false, false, EPI_TOPK_DENSE>(p, splits, s); break;
@@ -793,6 +829,8 @@ static int gemm_entry(const void* A, const void* B, void* C, const void* aux,
     if (!trans_b) PACED_CHECK_ARG((size_t)128 * ldb * 2 < 0x7FFFFFFFull, "paced_gemm_bf16: ldb too large");
     if (epilogue == EPI_RES_DROP || epilogue == EPI_MASK)
         PACED_CHECK_ARG(aux && ldaux % 4 == 0 && ((uintptr_t)aux & 7) == 0, "paced_gemm_bf16: epilogue %d needs an 8-byte aligned aux with ldaux%%4==0", epilogue);
+    if (epilogue == EPI_MASK_BITS || (epilogue == EPI_RELU_DROP && aux))
+        PACED_CHECK_ARG(aux && N % 8 == 0 && ldaux >= N / 8, "paced_gemm_bf16: the bit matrix needs N %% 8 == 0 and ldaux >= N/8 bytes per row");
     PACED_CHECK_ARG(splits >= 0, "paced_gemm_bf16: splits must be >= 0 (0 = choose automatically)");
     PACED_CHECK_ARG(splits <= 1 || epilogue == EPI_ATOMIC_F32, "paced_gemm_bf16: split contraction needs the atomic epilogue");
     if (epilogue != EPI_ATOMIC_F32) splits = 1;

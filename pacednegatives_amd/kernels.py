@@ -10,8 +10,8 @@ import torch
 
 from . import _lib
 
-EPI_BF16, EPI_RES_DROP, EPI_RELU_DROP, EPI_MASK, EPI_F32, EPI_ATOMIC_F32 = range(6)
-BF16, F32, I64, I32 = torch.bfloat16, torch.float32, torch.int64, torch.int32
+EPI_BF16, EPI_RES_DROP, EPI_RELU_DROP, EPI_MASK, EPI_F32, EPI_ATOMIC_F32, EPI_MASK_BITS = range(7)
+BF16, F32, I64, I32, U8 = torch.bfloat16, torch.float32, torch.int64, torch.int32, torch.uint8
 
 # When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
 # ((trans_a, trans_b, epilogue), algorithmic FLOPs, start, end) is appended (bench.py's roofline leg).
@@ -43,9 +43,15 @@ def _rows2d(t, name):
 
 def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, alpha=1.0, mask_scale=1.0,
          drop_p=0.0, drop_seed=0, splits=1):
-    """c = alpha * op(a) op(b) with a fused epilogue (see include/paced_hip.h)."""
+    """c = alpha * op(a) op(b) with a fused epilogue (see include/paced_hip.h).
+
+    aux is the bf16 residual / mask operand of EPI_RES_DROP / EPI_MASK, or a uint8 [M, N/8] bit matrix
+    (bit n%8 of byte n//8 of row m <-> element (m, n)): written by EPI_RELU_DROP with the sign of its
+    output, read by EPI_MASK_BITS.
+    """
     lib = _lib.load()
-    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(aux, BF16, "aux")
+    bits = epilogue in (EPI_RELU_DROP, EPI_MASK_BITS)
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(aux, U8 if bits else BF16, "aux")
     _chk(c, F32 if epilogue in (EPI_F32, EPI_ATOMIC_F32) else BF16, "c")
     lda, ldb, ldc = _rows2d(a, "a"), _rows2d(b, "b"), _rows2d(c, "c")
     M, N = c.shape
@@ -56,7 +62,9 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
         raise ValueError(f"b {tuple(b.shape)} does not give N={N}, K={K} (trans_b={trans_b})")
     ldaux = 0
     if aux is not None:
-        if tuple(aux.shape) != (M, N):
+        if bits and (N % 8 or tuple(aux.shape) != (M, N // 8)):
+            raise ValueError(f"the bit matrix must be [M, N/8] = [{M}, {N}/8], got {tuple(aux.shape)}")
+        if not bits and tuple(aux.shape) != (M, N):
             raise ValueError("aux must have the shape of c")
         ldaux = _rows2d(aux, "aux")
     prof = PROFILE

@@ -14,6 +14,7 @@ the backward pass from the same seeds.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -61,6 +62,7 @@ class _EncLayerSaved:
     ctx: torch.Tensor = None
     lse: torch.Tensor = None
     h_mid: torch.Tensor = None
+    actbits: torch.Tensor = None
     xn2: torch.Tensor = None
     rstd2: torch.Tensor = None
     act: torch.Tensor = None
@@ -128,6 +130,7 @@ class T5Engine:
         self.device = params.device
         self._bucket_cache: Dict[int, torch.Tensor] = {}
         self.force_kv_projection = False      # tests: take the explicit K/V projection path of the cross-attention
+        self.ffn_bit_mask = os.environ.get("PACED_FFN_BITMASK", "1") != "0"   # encoder FFN backward masks by saved sign bits
         self._bucket_dec = torch.tensor([0, 1], dtype=torch.int32, device=self.device)   # offsets 0 and -1 (HF:244-249)
         dec_b = relative_position_bucket(torch.tensor([0, -1]), False, dims.num_buckets, dims.max_distance)
         assert dec_b.tolist() == [0, 1]
@@ -206,12 +209,14 @@ class T5Engine:
             xn2, rstd2 = self._empty(M, d), torch.empty(M, dtype=F32, device=self.device)
             K.rmsnorm_fwd(h_mid, P.w(pre + "ln2"), xn2, rstd2, eps=dims.eps)
             act = self._empty(M, ff)
-            K.gemm(xn2, P.w(pre + "wi"), act, epilogue=K.EPI_RELU_DROP, drop_p=p, drop_seed=self._seed(st, _SITE_FF_ACT, l))
+            # the backward only needs to know which activations survived relu and dropout: one bit each
+            actbits = torch.empty(M, ff // 8, dtype=torch.uint8, device=self.device) if save and self.ffn_bit_mask and ff % 8 == 0 else None
+            K.gemm(xn2, P.w(pre + "wi"), act, epilogue=K.EPI_RELU_DROP, aux=actbits, drop_p=p, drop_seed=self._seed(st, _SITE_FF_ACT, l))
             h_out = self._empty(M, d)
             K.gemm(act, P.w(pre + "wo"), h_out, epilogue=K.EPI_RES_DROP, aux=h_mid, drop_p=p, drop_seed=self._seed(st, _SITE_FF_OUT, l))
             if save:
                 sv.h_in, sv.xn, sv.rstd1, sv.qkv, sv.ctx, sv.lse = h, xn, rstd1, qkv, ctx, lse
-                sv.h_mid, sv.xn2, sv.rstd2, sv.act = h_mid, xn2, rstd2, act
+                sv.h_mid, sv.xn2, sv.rstd2, sv.act, sv.actbits = h_mid, xn2, rstd2, act, actbits
                 st.enc_layers.append(sv)
             h = h_out
         enc = self._empty(M, d)
@@ -417,7 +422,10 @@ class T5Engine:
             z = dz if dz is not None else dh
             self._dweight(z, sv.act, pre + "wo")
             dact = self._empty(M, ff)
-            K.gemm(z, P.w(pre + "wo"), dact, trans_b=True, epilogue=K.EPI_MASK, aux=sv.act, mask_scale=scale)
+            if sv.actbits is not None:
+                K.gemm(z, P.w(pre + "wo"), dact, trans_b=True, epilogue=K.EPI_MASK_BITS, aux=sv.actbits, mask_scale=scale)
+            else:
+                K.gemm(z, P.w(pre + "wo"), dact, trans_b=True, epilogue=K.EPI_MASK, aux=sv.act, mask_scale=scale)
             self._dweight(dact, sv.xn2, pre + "wi")
             dxn = self._empty(M, d)
             K.gemm(dact, P.w(pre + "wi"), dxn, trans_b=True)

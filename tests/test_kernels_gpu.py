@@ -155,6 +155,37 @@ def test_gemm_epilogues(tile):
     assert torch.equal(out.float().cpu(), torch.where(res > 0, acc * 2.0, torch.zeros_like(acc)).to(torch.bfloat16).float())
 
 
+def unpack_bits(bits, N):
+    """[M, N/8] uint8 -> [M, N] bool, bit n%8 of byte n//8 <-> column n."""
+    sh = torch.arange(8, device=bits.device, dtype=torch.uint8)
+    return ((bits.unsqueeze(-1) >> sh) & 1).bool().reshape(bits.shape[0], -1)[:, :N]
+
+
+@pytest.mark.parametrize("shape", [(260, 256, 128), (515, 776, 64)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_gemm_sign_bit_matrix(shape, p, tile):
+    """relu+dropout writes one bit per output (output > 0); the bit-masked product equals the one masked by the
+    saved output itself, on ragged row counts and column counts that end inside a tile."""
+    M, N, Kc = shape
+    a, b = ints((M, Kc), -2, 2, 40), ints((N, Kc), -2, 2, 41)
+    act = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    plain = torch.empty_like(act)
+    bits = torch.full((M + 1, N // 8 + 1), 0xA5, device=DEV, dtype=torch.uint8)      # guard row and column
+    K.gemm(bf(a), bf(b), act, epilogue=K.EPI_RELU_DROP, aux=bits[:M, :N // 8], drop_p=p, drop_seed=77)
+    K.gemm(bf(a), bf(b), plain, epilogue=K.EPI_RELU_DROP, drop_p=p, drop_seed=77)
+    assert torch.equal(act, plain)
+    assert torch.equal(unpack_bits(bits[:M, :N // 8], N), act > 0)
+    assert (bits[M] == 0xA5).all() and (bits[:, N // 8] == 0xA5).all()
+    Kb = 64
+    g, w = ints((M, Kb), -2, 2, 42), ints((N, Kb), -2, 2, 43)
+    by_bits, by_act = torch.empty_like(act), torch.empty_like(act)
+    K.gemm(bf(g), bf(w), by_bits, epilogue=K.EPI_MASK_BITS, aux=bits[:M, :N // 8], mask_scale=1.5)
+    K.gemm(bf(g), bf(w), by_act, epilogue=K.EPI_MASK, aux=act, mask_scale=1.5)
+    assert torch.equal(by_bits, by_act)
+    want = torch.where(act.cpu() > 0, (g @ w.t()) * 1.5, torch.zeros(M, N))
+    assert torch.equal(by_bits.float().cpu(), want.to(torch.bfloat16).float())
+
+
 @pytest.mark.parametrize("splits", [1, 3, 8])
 def test_gemm_weight_gradient_atomic_split(splits, tile):
     Mtok, No, Ko = 1000, 136, 192                     # dW[No,Ko] = dY[Mtok,No]^T X[Mtok,Ko]
