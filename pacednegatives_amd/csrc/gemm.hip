@@ -468,32 +468,46 @@ __device__ __forceinline__ int ring_wrap(int x) { return x >= 10 ? x - 10 : x; }
 // wave's own 1 KiB pieces of the two ring slots that are dead at this point (the pieces the wave
 // itself overwrites with its next two LDS-DMAs), so no barrier is involved.  Values are rounded to
 // bf16 before the transposition: C = bf16(aux + bf16(dropout(acc))) for the residual form.
-template <int EPI>
-__device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int m0, int n0, int wr, int wc, int lane,
-                                              f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
+// The residual / mask operand is loaded by inline-asm statements: next to LDS-DMA the compiler answers any
+// register-destination load it can see with `s_waitcnt vmcnt(0)` ahead of every LDS read of the kernel, the
+// K loop's included, which drains the DMA ring once per K step.  Hidden loads are counted by hand instead.
+// FULL (the tile lies inside the matrix): every lane issues 16 loads, then one store per 16-row half-block, so
+// when half-block n is consumed the younger operations in flight are 15 - n loads and n stores: vmcnt(15)
+// throughout.  Edge tiles clamp the load addresses into the matrix, wait for all loads once and predicate the stores.
+#define PACED_AUX15(X) X(0,1) X(1,0) X(1,1) X(2,0) X(2,1) X(3,0) X(3,1) X(4,0) X(4,1) X(5,0) X(5,1) X(6,0) X(6,1) X(7,0) X(7,1)
+template <int EPI, bool FULL>
+__device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb, int m0, int n0, int wr, int wc, int lane,
+                                                   f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
+    constexpr bool LOADS = (EPI == EPI_RES_DROP || EPI == EPI_MASK || EPI == EPI_MASK_BITS);
     const int rr = lane >> 3, c = lane & 7;
     const int ncol = n0 + wc * 64 + c * 8;
-    const bool col_ok = ncol < p.N;                   // N is a multiple of 8 on this path
-    unsigned int mbits[8][2];
-    if (EPI == EPI_MASK_BITS) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
-                mbits[i][q] = (m < p.M && col_ok) ? reinterpret_cast<const unsigned char*>(p.aux)[(size_t)m * p.ldaux + (ncol >> 3)] : 0u;
-            }
-    }
+    const bool col_ok = FULL || ncol < p.N;           // N is a multiple of 8 on this path
+    uint32_t mbits[8][2];
     bf16x8 aux[8][2];
-    if (EPI == EPI_RES_DROP || EPI == EPI_MASK) {
+    if (LOADS) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
-                aux[i][q] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (m < p.M && col_ok) aux[i][q] = *reinterpret_cast<const bf16x8*>(p.aux + (size_t)m * p.ldaux + ncol);
+                const int mc = FULL ? m : min(m, p.M - 1);
+                const int nc = col_ok ? ncol : 0;
+                if (EPI == EPI_MASK_BITS) {
+                    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.aux) + (size_t)mc * p.ldaux + (nc >> 3);
+                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(mbits[i][q]) : "v"(src) : "memory");
+                } else {
+                    const bf16* src = p.aux + (size_t)mc * p.ldaux + nc;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aux[i][q]) : "v"(src) : "memory");
+                }
             }
+        if (!FULL) {
+#define PACED_AUX_OPERAND(i, q) , "+v"(aux[i][q])
+#define PACED_BITS_OPERAND(i, q) , "+v"(mbits[i][q])
+            if (EPI == EPI_MASK_BITS) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbits[0][0]) PACED_AUX15(PACED_BITS_OPERAND) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(aux[0][0]) PACED_AUX15(PACED_AUX_OPERAND) :: "memory");
+#undef PACED_AUX_OPERAND
+#undef PACED_BITS_OPERAND
+        }
     }
     const int mw = lane & 15, g = lane >> 4;
     const int wsw = ((mw & 7) << 1) | (mw >> 3);
@@ -534,6 +548,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int
         for (int q = 0; q < 2; ++q) {
             bf16x8 t = *reinterpret_cast<const bf16x8*>((q ? pb : pa) + roff);
             if (q) t = __builtin_shufflevector(t, t, 4, 5, 6, 7, 0, 1, 2, 3);      // rows 8..15 were stored with their 8-byte halves swapped
+            if (LOADS && FULL) {
+                if (EPI == EPI_MASK_BITS) asm volatile("s_waitcnt vmcnt(15)" : "+v"(mbits[i][q]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(15)" : "+v"(aux[i][q]) :: "memory");
+            }
             if (EPI == EPI_RES_DROP) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = f2bf(bf2f(aux[i][q][e]) + bf2f(t[e]));
@@ -545,15 +563,25 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int
                 for (int e = 0; e < 8; ++e) t[e] = ((mbits[i][q] >> e) & 1u) ? t[e] : (bf16)0.f;
             }
             const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
-            if (EPI == EPI_RELU_DROP && p.aux && m < p.M && col_ok) {
+            const bool ok = FULL || (m < p.M && col_ok);
+            if (EPI == EPI_RELU_DROP && p.aux && ok) {
                 unsigned int byte = 0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) byte |= (bf2f(t[e]) > 0.f ? 1u : 0u) << e;
                 const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (ncol >> 3)] = (unsigned char)byte;
             }
-            if (m < p.M && col_ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
+            if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
         }
     }
+}
+#undef PACED_AUX15
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int m0, int n0, int wr, int wc, int lane,
+                                              f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
+    constexpr bool LOADS = (EPI == EPI_RES_DROP || EPI == EPI_MASK || EPI == EPI_MASK_BITS);
+    if (LOADS && m0 + 256 <= p.M && n0 + 256 <= p.N) epilogue_rows_impl<EPI, true>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3);
+    else epilogue_rows_impl<EPI, false>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3);
 }
 
 template <bool TA, bool TB, int EPI>

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Audit of the hidden (inline-asm) register loads in the device assembly of gemm.hip.
+
+The compiler treats the destination of an asm load as written when the statement ends, so it is free to copy,
+spill or reuse those registers before the data has landed.  This script walks the .s text in program order and
+reports every instruction that touches the destination registers of an asm `global_load_*` between the load and
+the hand-written `s_waitcnt vmcnt(N)` that releases it (vmcnt(15): the oldest pending load; vmcnt(0): all).
+
+usage: audit_asm_loads.py gemm.s      (hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S gemm.hip)
+"""
+import re
+import sys
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def main(path):
+    kernel, in_asm, pending, bad, loads = None, False, [], 0, 0
+    for ln, line in enumerate(open(path), 1):
+        s = line.strip()
+        if s.startswith("_Z") and ":" in s.split(";")[0]:
+            kernel, pending = s.split(":")[0], []
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        code = s.split(";")[0]
+        if in_asm and code.startswith("global_load_"):
+            dst = code.split(",")[0]
+            # the address operand must not be the destination of an older pending load; its own destination may overlap it
+            addr = regs_of(",".join(code.split(",")[1:]))
+            for at, d in pending:
+                if addr & d:
+                    bad += 1
+                    print(f"{path}:{ln}: {kernel}: address uses v{sorted(addr & d)} of the load at line {at} before its wait: {s}")
+            pending.append((ln, regs_of(dst)))
+            loads += 1
+            continue
+        elif in_asm and code.startswith("s_waitcnt vmcnt("):
+            n = int(code[len("s_waitcnt vmcnt("):].split(")")[0])
+            if n == 0:
+                pending = []
+            elif n == 15 and pending:
+                pending.pop(0)
+            continue
+        if code.startswith("s_endpgm"):
+            pending = []
+        used = regs_of(code)
+        for at, dst in pending:
+            hit = used & dst
+            if hit:
+                bad += 1
+                print(f"{path}:{ln}: {kernel}: touches v{sorted(hit)} of the load at line {at} before its wait: {s}")
+    print(f"{loads} hidden loads, {bad} violations")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

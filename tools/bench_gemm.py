@@ -20,6 +20,15 @@ SHAPES = [  # (name, ta, tb, epi, rows_out, cols_out, contraction)
     ("dWqkv TN", 1, 1, K.EPI_ATOMIC_F32, 2304, 768, M),
     ("dWo   TN", 1, 1, K.EPI_ATOMIC_F32, 768, 768, M),
 ]
+if os.environ.get("EXTRA"):     # the same products with cheaper epilogues: what each epilogue costs
+    SHAPES += [
+        ("o     NT plain", 0, 0, K.EPI_BF16, M, 768, 768),
+        ("o     NT res p=0", 0, 0, K.EPI_RES_DROP, M, 768, 768),
+        ("wi    NT plain", 0, 0, K.EPI_BF16, M, 3072, 768),
+        ("wi    NT relu p=0", 0, 0, K.EPI_RELU_DROP, M, 3072, 768),
+        ("dact  NN bits", 0, 1, K.EPI_MASK_BITS, M, 3072, 768),
+        ("dact  NN plain", 0, 1, K.EPI_BF16, M, 3072, 768),
+    ]
 
 
 def splits_for(rows, cols, contraction, tile):
@@ -41,7 +50,9 @@ def main():
         b = rn(Kc, C) if tb else rn(C, Kc)
         out = torch.zeros(R, C, device=dev, dtype=torch.float32 if epi in (K.EPI_F32, K.EPI_ATOMIC_F32) else torch.bfloat16)
         aux = rn(R, C) if epi in (K.EPI_RES_DROP, K.EPI_MASK) else None
-        drop = 0.1 if epi in (K.EPI_RES_DROP, K.EPI_RELU_DROP) else 0.0
+        if epi == K.EPI_MASK_BITS:
+            aux = torch.randint(0, 256, (R, C // 8), device=dev, dtype=torch.uint8)
+        drop = 0.1 if epi in (K.EPI_RES_DROP, K.EPI_RELU_DROP) and "p=0" not in name else 0.0
         for rnd in range(3):
             for tile in TILES:
                 K.gemm_set_tile(tile)
