@@ -255,11 +255,23 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, void* Cb, int m0, 
                                          f32x4 (&acc)[Cfg::MI][Cfg::NJ]) {
     constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
     if (EPI == EPI_TOPK_DENSE || EPI == EPI_TOPK_FILTER) {
+        // The filter's thresholds and its slot counter go through inline-asm statements that wait for themselves:
+        // a register-destination load or returning atomic the compiler can see makes it put `s_waitcnt vmcnt(0)`
+        // ahead of every LDS read of the kernel, which drains the K loop's LDS-DMA ring once per K step.
+        float thr[NJ];
+        if (EPI == EPI_TOPK_FILTER) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float* src = p.tk_thr + min(n0 + Cfg::noff(wn, j) + (lane & 15), p.N - 1);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(thr[j]) : "v"(src) : "memory");
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(thr[j]) :: "memory");
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = n0 + Cfg::noff(wn, j) + (lane & 15);
             if (n >= p.N) continue;
-            const float thr = (EPI == EPI_TOPK_FILTER) ? p.tk_thr[n] : 0.f;
             unsigned long long* cand = p.tk_cand + (size_t)n * p.tk_cap;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -270,8 +282,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, void* Cb, int m0, 
                     const float sc = acc[i][j][r];
                     if (EPI == EPI_TOPK_DENSE) {
                         cand[m] = topk_key(sc, p.tk_row_base + (unsigned int)m);
-                    } else if (sc >= thr) {
-                        const unsigned int pos = atomicAdd(p.tk_cnt + n, 1u);
+                    } else if (sc >= thr[j]) {
+                        unsigned int pos;
+                        const unsigned int one = 1u;
+                        unsigned int* slot = p.tk_cnt + n;
+                        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(pos) : "v"(slot), "v"(one) : "memory");
                         if (pos < (unsigned int)p.tk_cap) cand[pos] = topk_key(sc, p.tk_row_base + (unsigned int)m);
                     }
                 }
