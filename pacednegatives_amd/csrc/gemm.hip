@@ -714,6 +714,10 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
             quadrant_mfma<NATURAL>(fa, fb0, acc, 1, 0);
             PACED_PINNED_BARRIER();
         }
+        // The second wave group still owes the barrier that ends its last phase.  Join it here, so that both groups
+        // run their epilogues side by side; otherwise that barrier is met by this group's first barrier of the next
+        // item, and each group sits idle through the other's whole epilogue.
+        if (wr == 0) __builtin_amdgcn_s_barrier();
         if (EPI == EPI_BF16 || EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP || EPI == EPI_MASK || EPI == EPI_MASK_BITS) {
             char* s1 = sw + ring_wrap(base + 8) * HALF;      // the finished K step's B half 1 and A half 1 slots
             char* s2 = sw + ring_wrap(base + 9) * HALF;
@@ -737,8 +741,8 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
             const int kb = split * p.k_per_split, ke = min(p.K, kb + p.k_per_split);
             nsteps = (ke - kb + BK - 1) / BK;
         }
+        if (wr == 1) __builtin_amdgcn_s_barrier();       // fall one barrier behind again
     }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
