@@ -486,10 +486,25 @@ __device__ __forceinline__ int ring_wrap(int x) { return x >= 10 ? x - 10 : x; }
 // The residual / mask operand is loaded by inline-asm statements: next to LDS-DMA the compiler answers any
 // register-destination load it can see with `s_waitcnt vmcnt(0)` ahead of every LDS read of the kernel, the
 // K loop's included, which drains the DMA ring once per K step.  Hidden loads are counted by hand instead.
-// FULL (the tile lies inside the matrix): every lane issues 16 loads, then one store per 16-row half-block, so
-// when half-block n is consumed the younger operations in flight are 15 - n loads and n stores: vmcnt(15)
-// throughout.  Edge tiles clamp the load addresses into the matrix, wait for all loads once and predicate the stores.
-#define PACED_AUX15(X) X(0,1) X(1,0) X(1,1) X(2,0) X(2,1) X(3,0) X(3,1) X(4,0) X(4,1) X(5,0) X(5,1) X(6,0) X(6,1) X(7,0) X(7,1)
+// A lane consumes 16 pieces (one per 8-row half-block, n = 0..15), eight of them in flight at a time: loads 0-7 go
+// out first, and load n + 8 is issued right after the store of half-block n into the registers that n has freed.
+// FULL (the tile lies inside the matrix; every store is issued): when piece n is consumed the operations younger
+// than its load are loads n+1 .. min(n+7, 15) and the stores issued since, n of them for n < 8 and 7 after that.
+// Edge tiles clamp the load addresses into the matrix, predicate the stores and wait for each batch of eight whole.
+template <class T>
+__device__ __forceinline__ void wait_hidden_load(int n, T& x) {
+#define PACED_WAIT_CASE(N, CNT) if (n == N) asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(x) :: "memory");
+    PACED_WAIT_CASE(0, 7) PACED_WAIT_CASE(1, 8) PACED_WAIT_CASE(2, 9) PACED_WAIT_CASE(3, 10)
+    PACED_WAIT_CASE(4, 11) PACED_WAIT_CASE(5, 12) PACED_WAIT_CASE(6, 13) PACED_WAIT_CASE(7, 14)
+    PACED_WAIT_CASE(8, 14) PACED_WAIT_CASE(9, 13) PACED_WAIT_CASE(10, 12) PACED_WAIT_CASE(11, 11)
+    PACED_WAIT_CASE(12, 10) PACED_WAIT_CASE(13, 9) PACED_WAIT_CASE(14, 8) PACED_WAIT_CASE(15, 7)
+#undef PACED_WAIT_CASE
+}
+template <class T>
+__device__ __forceinline__ void wait_hidden_batch(T (&x)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) :: "memory");
+}
+
 template <int EPI, bool FULL>
 __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb, int m0, int n0, int wr, int wc, int lane,
                                                    f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
@@ -497,105 +512,120 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
     const int rr = lane >> 3, c = lane & 7;
     const int ncol = n0 + wc * 64 + c * 8;
     const bool col_ok = FULL || ncol < p.N;           // N is a multiple of 8 on this path
-    uint32_t mbits[8][2];
-    bf16x8 aux[8][2];
+    uint32_t mbits[8];
+    bf16x8 aux[8];
+    auto load_piece = [&](int n) {
+        const int m = m0 + CfgPhased::moff(wr, n >> 1) + (n & 1) * 8 + rr;
+        const int mc = FULL ? m : min(m, p.M - 1);
+        const int nc = col_ok ? ncol : 0;
+        if (EPI == EPI_MASK_BITS) {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(p.aux) + (size_t)mc * p.ldaux + (nc >> 3);
+            asm volatile("global_load_ubyte %0, %1, off" : "=v"(mbits[n & 7]) : "v"(src) : "memory");
+        } else {
+            const bf16* src = p.aux + (size_t)mc * p.ldaux + nc;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aux[n & 7]) : "v"(src) : "memory");
+        }
+    };
+    auto wait_batch = [&]() {
+        if (EPI == EPI_MASK_BITS) wait_hidden_batch(mbits);
+        else wait_hidden_batch(aux);
+    };
     if (LOADS) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
-                const int mc = FULL ? m : min(m, p.M - 1);
-                const int nc = col_ok ? ncol : 0;
-                if (EPI == EPI_MASK_BITS) {
-                    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.aux) + (size_t)mc * p.ldaux + (nc >> 3);
-                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(mbits[i][q]) : "v"(src) : "memory");
-                } else {
-                    const bf16* src = p.aux + (size_t)mc * p.ldaux + nc;
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aux[i][q]) : "v"(src) : "memory");
-                }
-            }
-        if (!FULL) {
-#define PACED_AUX_OPERAND(i, q) , "+v"(aux[i][q])
-#define PACED_BITS_OPERAND(i, q) , "+v"(mbits[i][q])
-            if (EPI == EPI_MASK_BITS) asm volatile("s_waitcnt vmcnt(0)" : "+v"(mbits[0][0]) PACED_AUX15(PACED_BITS_OPERAND) :: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(aux[0][0]) PACED_AUX15(PACED_AUX_OPERAND) :: "memory");
-#undef PACED_AUX_OPERAND
-#undef PACED_BITS_OPERAND
-        }
+        for (int n = 0; n < 8; ++n) load_piece(n);
+        if (!FULL) wait_batch();
     }
     const int mw = lane & 15, g = lane >> 4;
     const int wsw = ((mw & 7) << 1) | (mw >> 3);
     const int woff = (mw & 7) * 128;
     const int roff = rr * 128 + ((c ^ rr) << 4);
     const bool has_drop = (EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP) && p.drop.thresh != 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        char* pa = (i & 1) ? pc2 : pc0;
-        char* pb = (i & 1) ? pc3 : pc1;
-        char* pw = (mw < 8 ? pa : pb) + woff;
+    const float scale = (EPI == EPI_MASK || EPI == EPI_MASK_BITS) ? p.alpha * p.mask_scale : p.alpha;
+
+    // 16-row block i as bf16 in the MFMA layout (4 consecutive columns of one row per lane and 16-column group)
+    auto convert = [&](int i, bf16x4 (&o)[4]) {
         const uint64_t drow = (uint64_t)(m0 + CfgPhased::moff(wr, i) + mw) * (uint64_t)p.N + (uint64_t)(n0 + wc * 64 + g * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-            if (EPI == EPI_RELU_DROP) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (EPI == EPI_MASK || EPI == EPI_MASK_BITS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= p.mask_scale;
-            }
+            f32x4 v = acc[i][j] * scale;
+            if (EPI == EPI_RELU_DROP) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
             if (has_drop) {
                 float f[4];
                 drop_factor4(p.drop, drow + j * 16, f);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= f[r];
+                v *= f32x4{f[0], f[1], f[2], f[3]};
             }
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-            *reinterpret_cast<bf16x4*>(pw + (((j * 4 + g) ^ wsw) << 3)) = o;
+            o[j] = __builtin_convertvector(v, bf16x4);
         }
+    };
+    // ... written to the wave's staging pieces (rows 0-7 to one, 8-15 to the other, 8-byte units swizzled)
+    auto stage = [&](int i, const bf16x4 (&o)[4]) {
+        char* pw = (mw < 8 ? ((i & 1) ? pc2 : pc0) : ((i & 1) ? pc3 : pc1)) + woff;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            bf16x8 t = *reinterpret_cast<const bf16x8*>((q ? pb : pa) + roff);
-            if (q) t = __builtin_shufflevector(t, t, 4, 5, 6, 7, 0, 1, 2, 3);      // rows 8..15 were stored with their 8-byte halves swapped
-            if (LOADS && FULL) {
-                if (EPI == EPI_MASK_BITS) asm volatile("s_waitcnt vmcnt(15)" : "+v"(mbits[i][q]) :: "memory");
-                else asm volatile("s_waitcnt vmcnt(15)" : "+v"(aux[i][q]) :: "memory");
-            }
-            if (EPI == EPI_RES_DROP) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = f2bf(bf2f(aux[i][q][e]) + bf2f(t[e]));
-            } else if (EPI == EPI_MASK) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = bf2f(aux[i][q][e]) > 0.f ? t[e] : (bf16)0.f;
-            } else if (EPI == EPI_MASK_BITS) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = ((mbits[i][q] >> e) & 1u) ? t[e] : (bf16)0.f;
-            }
-            const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
-            const bool ok = FULL || (m < p.M && col_ok);
-            if (EPI == EPI_RELU_DROP && p.aux && ok) {
-                unsigned int byte = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) byte |= (bf2f(t[e]) > 0.f ? 1u : 0u) << e;
-                const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (ncol >> 3)] = (unsigned char)byte;
-            }
-            if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<bf16x4*>(pw + (((j * 4 + g) ^ wsw) << 3)) = o[j];
+    };
+    // ... and read back with 8 lanes covering a 128-byte row: lane (rr, c) gets columns 8c..8c+7 of rows rr and 8+rr
+    auto finish = [&](int i, int q, bf16x8 t) {
+        if (q) t = __builtin_shufflevector(t, t, 4, 5, 6, 7, 0, 1, 2, 3);      // rows 8..15 were stored with their 8-byte halves swapped
+        const int n = i * 2 + q;
+        if (LOADS && FULL) {
+            if (EPI == EPI_MASK_BITS) wait_hidden_load(n, mbits[n & 7]);
+            else wait_hidden_load(n, aux[n & 7]);
         }
+        if (EPI == EPI_RES_DROP) {
+            const bf16x8 x = aux[n & 7];
+            const bf16x4 lo = __builtin_convertvector(__builtin_convertvector(__builtin_shufflevector(x, x, 0, 1, 2, 3), f32x4) +
+                                                      __builtin_convertvector(__builtin_shufflevector(t, t, 0, 1, 2, 3), f32x4), bf16x4);
+            const bf16x4 hi = __builtin_convertvector(__builtin_convertvector(__builtin_shufflevector(x, x, 4, 5, 6, 7), f32x4) +
+                                                      __builtin_convertvector(__builtin_shufflevector(t, t, 4, 5, 6, 7), f32x4), bf16x4);
+            t = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        } else if (EPI == EPI_MASK) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = bf2f(aux[n & 7][e]) > 0.f ? t[e] : (bf16)0.f;
+        } else if (EPI == EPI_MASK_BITS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = ((mbits[n & 7] >> e) & 1u) ? t[e] : (bf16)0.f;
+        }
+        const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
+        const bool ok = FULL || (m < p.M && col_ok);
+        if (EPI == EPI_RELU_DROP && p.aux && ok) {
+            unsigned int byte = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) byte |= (bf2f(t[e]) > 0.f ? 1u : 0u) << e;
+            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (ncol >> 3)] = (unsigned char)byte;
+        }
+        if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
+        if (LOADS && n < 8) {
+            if (FULL) load_piece(n + 8);
+            else if (n == 7) {
+#pragma unroll
+                for (int k = 8; k < 16; ++k) load_piece(k);
+                wait_batch();
+            }
+        }
+    };
+
+    // Pipelined over the eight blocks: the LDS reads of block i are in flight while block i+1 is converted and written
+    // to the other pair of pieces; only then are the reads waited for.
+    bf16x4 o[4];
+    convert(0, o);
+    stage(0, o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(((i & 1) ? pc2 : pc0) + roff);
+        const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(((i & 1) ? pc3 : pc1) + roff);
+        if (i + 1 < 8) {
+            convert(i + 1, o);
+            stage(i + 1, o);
+        }
+        finish(i, 0, t0);
+        finish(i, 1, t1);
     }
 }
-#undef PACED_AUX15
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int m0, int n0, int wr, int wc, int lane,
                                               f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
-    constexpr bool LOADS = (EPI == EPI_RES_DROP || EPI == EPI_MASK || EPI == EPI_MASK_BITS);
-    if (LOADS && m0 + 256 <= p.M && n0 + 256 <= p.N) epilogue_rows_impl<EPI, true>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3);
+    if (m0 + 256 <= p.M && n0 + 256 <= p.N) epilogue_rows_impl<EPI, true>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3);
     else epilogue_rows_impl<EPI, false>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3);
 }
 

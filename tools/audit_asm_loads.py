@@ -4,7 +4,9 @@
 The compiler treats the destination of an asm load as written when the statement ends, so it is free to copy,
 spill or reuse those registers before the data has landed.  This script walks the .s text in program order and
 reports every instruction that touches the destination registers of an asm `global_load_*` between the load and
-the hand-written `s_waitcnt vmcnt(N)` that releases it (vmcnt(15): the oldest pending load; vmcnt(0): all).
+the hand-written `s_waitcnt vmcnt(N)` that releases it (a counted wait releases the oldest pending load, vmcnt(0)
+all of them), and checks every counted wait: N must not exceed the number of vector-memory instructions issued after
+the load it releases, or the wait could return before the data has landed.
 
 usage: audit_asm_loads.py gemm.s      (hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S gemm.hip)
 """
@@ -25,7 +27,7 @@ def regs_of(text):
 
 
 def main(path):
-    kernel, in_asm, pending, bad, loads = None, False, [], 0, 0
+    kernel, in_asm, pending, bad, loads, vm_seq = None, False, [], 0, 0, 0
     for ln, line in enumerate(open(path), 1):
         s = line.strip()
         if s.startswith("_Z") and ":" in s.split(";")[0]:
@@ -40,28 +42,33 @@ def main(path):
         if not s or s.startswith(";") or s.startswith("."):
             continue
         code = s.split(";")[0]
+        if re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", code):
+            vm_seq += 1
         if in_asm and code.startswith("global_load_"):
             dst = code.split(",")[0]
             # the address operand must not be the destination of an older pending load; its own destination may overlap it
             addr = regs_of(",".join(code.split(",")[1:]))
-            for at, d in pending:
+            for at, d, _ in pending:
                 if addr & d:
                     bad += 1
                     print(f"{path}:{ln}: {kernel}: address uses v{sorted(addr & d)} of the load at line {at} before its wait: {s}")
-            pending.append((ln, regs_of(dst)))
+            pending.append((ln, regs_of(dst), vm_seq))
             loads += 1
             continue
         elif in_asm and code.startswith("s_waitcnt vmcnt("):
             n = int(code[len("s_waitcnt vmcnt("):].split(")")[0])
             if n == 0:
                 pending = []
-            elif n == 15 and pending:
-                pending.pop(0)
+            elif pending:
+                at, _, seq = pending.pop(0)
+                if n > vm_seq - seq:
+                    bad += 1
+                    print(f"{path}:{ln}: {kernel}: vmcnt({n}) releases the load at line {at}, but only {vm_seq - seq} vector-memory instructions follow it")
             continue
         if code.startswith("s_endpgm"):
             pending = []
         used = regs_of(code)
-        for at, dst in pending:
+        for at, dst, _ in pending:
             hit = used & dst
             if hit:
                 bad += 1
