@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpaced_hip.so")
+# PACED_HIP_LIB selects another build of the same library (A/B runs of two builds in one job)
+LIB_PATH = os.environ.get("PACED_HIP_LIB") or os.path.join(_HERE, "lib", "libpaced_hip.so")
 
 _vp, _i, _f, _u32, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, C.c_longlong
 
