@@ -136,8 +136,30 @@ class LCEDataset(Dataset):
         self.round = torch.floor
         self.min = min
         self.max = max
+        self._shared_pace = None
         self.weight = init_weight
         self._pace_cache = (None, None)    # (clipped pace, probabilities): items of one batch share a pace
+
+    # The pace is a plain attribute in the reference, so DataLoader workers sample from their own stale copy of it
+    # (``lceT5.py:77-80`` writes the parent's).  After ``share_pace()`` it lives in shared memory instead and a write
+    # in the training process reaches every worker.
+    @property
+    def weight(self):
+        return float(self._shared_pace[0]) if self._shared_pace is not None else self._weight
+
+    @weight.setter
+    def weight(self, value):
+        if self._shared_pace is not None:
+            self._shared_pace[0] = float(value)
+        else:
+            self._weight = value
+
+    def share_pace(self):
+        if self._shared_pace is None:
+            cell = torch.zeros(1, dtype=torch.float64).share_memory_()
+            cell[0] = float(self._weight)
+            self._shared_pace = cell
+        return self
 
     def get(self, idx):
         return self.data[idx[0]], [self.docs[x] for x in self.neg_idx[idx[0]][idx[1]].tolist()]

@@ -39,8 +39,15 @@ class _HParams(dict):
 # ----------------------------------------------------------------------------------------- data module
 class LCEDataModule:
     def __init__(self, data_dir: str = "path/to/dir", corpus: Any = "msmarco-passage", tokenizer: Any = None,
-                 batch_size: int = 32, shuffle=False, use_max=False, var=0.01, n=2, init_weight=0. + 1e-10, num_workers=4):
+                 batch_size: int = 32, shuffle=False, use_max=False, var=0.01, n=2, init_weight=0. + 1e-10, num_workers=4,
+                 token_store: str = None, propagate_pace: bool = False, seed: int = 0):
+        """Arguments as the reference's (``lceT5.py:14-24``) plus three that default to its behaviour:
+        ``token_store`` (directory of a ``fastdata.TokenStore``: batches are then assembled in the training process
+        from pre-tokenised text, one vectorised draw per batch), ``propagate_pace`` (the pace written by
+        ``ChangeDifficulty`` reaches the sampling code; in the reference, worker processes keep the initial pace) and
+        ``seed`` of the vectorised sampler."""
         self.data_dir = data_dir
+        self.token_store, self.propagate_pace, self.seed = token_store, propagate_pace, seed
         if isinstance(corpus, str):
             try:
                 import ir_datasets as irds
@@ -83,12 +90,18 @@ class LCEDataModule:
         self.neg_idx = [[str(x) for x in r["doc_id_b"]] for r in records]
         self.dataset = LCEDataset(self.pairs, self.neg_idx, self.corpus, self.tokenizer, self.weight, self.batch_size,
                                   var=self.var, n=self.n, min=0. + 1e-10, max=1.0 - 1e-10, use_max=self.use_max)
+        if self.propagate_pace:
+            self.dataset.share_pace()
 
     def train_dataloader(self, rank: int = 0, world_size: int = 1):
         """Sequential loader; with ``world_size`` > 1 rank r reads items r, r+W, ... (what Lightning's
         non-shuffling DistributedSampler gives each rank); ``batch_size`` is per rank."""
         from torch.utils.data import DataLoader, Subset
         ds = self.dataset
+        if self.token_store is not None:
+            from .fastdata import PacedBatchLoader, TokenStore
+            return PacedBatchLoader(ds, self.pairs, self.neg_idx, TokenStore.open(self.token_store), self.batch_size,
+                                    rank=rank, world_size=world_size, seed=self.seed, propagate_pace=self.propagate_pace)
         view = ds if world_size == 1 else Subset(ds, parallel.shard_indices(len(ds), rank, world_size))
         loader = DataLoader(view, batch_size=self.batch_size, num_workers=self.num_workers, collate_fn=self.collate(),
                             pin_memory=torch.cuda.is_available())

@@ -1,0 +1,204 @@
+"""Host input pipeline: vectorised pace sampler, pre-tokenised corpus, in-process batch loader.
+
+The sampler is checked against the exact successive-sampling probabilities and against the oracle's restatement
+of the reference sampler (``oracle/sampler_ref.py``, which follows ``pacednegatives/dataloader.py:134-151``) in
+distribution: the two consume different random streams, so index streams cannot be equal."""
+import collections
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sampler_ref
+from pacednegatives_amd import synthetic
+from pacednegatives_amd.dataloader import format_pair
+from pacednegatives_amd.fastdata import PacedBatchLoader, TokenStore, gumbel_top_n
+from pacednegatives_amd.lceT5 import ChangeDifficulty, LCEDataModule
+from pacednegatives_amd.tokenizer import EOS_ID, FALSE_ID, PAD_ID, TRUE_ID, SyntheticTokenizer
+
+
+def successive_sampling_probability(p, seq):
+    rest, out = 1.0, 1.0
+    for i in seq:
+        out *= p[i] / rest
+        rest -= p[i]
+    return out
+
+
+def test_gumbel_top_n_has_the_successive_sampling_distribution():
+    p = np.array([0.4, 0.25, 0.0, 0.2, 0.1, 0.05])
+    draws = 300_000
+    x = gumbel_top_n(p, 3, draws, np.random.default_rng(1))
+    assert x.shape == (draws, 3) and x.dtype == np.int64
+    assert (np.sort(x, axis=1)[:, 1:] != np.sort(x, axis=1)[:, :-1]).all()          # distinct
+    assert not (x == 2).any()                                                       # zero-probability entry
+    freq = collections.Counter(map(tuple, x.tolist()))
+    for seq in itertools.permutations([0, 1, 3, 4, 5], 3):
+        want = successive_sampling_probability(p, seq)
+        got = freq[seq] / draws
+        assert abs(got - want) < 5 * np.sqrt(want / draws) + 1e-4, (seq, got, want)
+
+
+def test_gumbel_top_n_matches_reference_sampler_in_distribution():
+    """Same inclusion frequency per index and same first-pick frequency as numpy's choice driven the reference's way."""
+    n_neg, n, var, mean, draws = 30, 4, 0.01, 0.3466, 40_000
+    p = sampler_ref.pace_probabilities(mean, n_neg, var)
+    rs = np.random.RandomState(5)
+    ref = np.stack([sampler_ref.sample(mean, n_neg, n, var, rng=rs) for _ in range(draws)])
+    fast = gumbel_top_n(p, n, draws, np.random.default_rng(6))
+    for col in (slice(None), slice(0, 1)):
+        a = np.bincount(ref[:, col].ravel(), minlength=n_neg) / draws
+        b = np.bincount(fast[:, col].ravel(), minlength=n_neg) / draws
+        assert np.abs(a - b).max() < 6 * np.sqrt(0.25 / draws)
+
+
+def test_gumbel_top_n_fails_like_choice_when_the_support_is_too_small():
+    p = sampler_ref.pace_probabilities(1e-10, 1000, 0.01)
+    live = int((p > 0).sum())
+    assert live < 1000
+    gumbel_top_n(p, live, 2, np.random.default_rng(0))
+    with pytest.raises(ValueError, match="Fewer non-zero entries"):
+        gumbel_top_n(p, live + 1, 2, np.random.default_rng(0))
+    with pytest.raises(ValueError):
+        np.random.RandomState(0).choice(np.arange(1000), size=(live + 1,), replace=False, p=p)
+
+
+@pytest.fixture()
+def dataset(tmp_path):
+    path, corpus = synthetic.write_synthetic_dataset(str(tmp_path), n_records=23, n_neg=40, seed=3)
+    # texts with irregular whitespace and punctuation at the joints
+    corpus._docs[0]["text"] = "  leading space, and a trailing one.  "
+    corpus._queries[0]["text"] = "what  is\tthis ?"
+    tok = SyntheticTokenizer()
+    store_dir = str(tmp_path / "tokens")
+    TokenStore.build(corpus, tok, store_dir)
+    return path, corpus, tok, store_dir
+
+
+def test_token_store_reproduces_the_formatted_string(dataset):
+    _path, corpus, tok, store_dir = dataset
+    store = TokenStore.open(store_dir)
+    docs = {d["doc_id"]: d["text"] for d in corpus.docs_iter()}
+    queries = {q["query_id"]: q["text"] for q in corpus.queries_iter()}
+    assert len(store.docs) == len(docs) and len(store.queries) == len(queries)
+    for qid, did in [("q0", "d0"), ("q0", "d7"), ("q5", "d0"), ("q11", "d99")]:
+        want = tok([format_pair(queries[qid], docs[did])])["input_ids"][0]
+        got = store.sequence(qid, did)
+        assert got.dtype == np.int32 and got[-1] == EOS_ID
+        assert got.tolist() == want.tolist()
+    with pytest.raises(FileNotFoundError):
+        TokenStore.open(store_dir + "_missing")
+
+
+def module(path, corpus, tok, **kw):
+    dm = LCEDataModule(path, corpus, tok, batch_size=4, n=3, var=0.01, init_weight=0.3466, num_workers=0, **kw)
+    dm.setup()
+    return dm
+
+
+def test_batch_loader_gives_the_collate_layout(dataset):
+    path, corpus, tok, store_dir = dataset
+    fast = module(path, corpus, tok, token_store=store_dir, propagate_pace=True, seed=11)
+    slow = module(path, corpus, tok)
+    fl, sl = fast.train_dataloader(), slow.train_dataloader()
+    assert isinstance(fl, PacedBatchLoader) and len(fl) == len(sl) == 6
+    docs = {d["doc_id"]: d["text"] for d in corpus.docs_iter()}
+    queries = {q["query_id"]: q["text"] for q in corpus.queries_iter()}
+    n_items = 0
+    for bi, ((fp, fn), (sp, sn)) in enumerate(zip(fl, sl)):
+        B = fp["input_ids"].shape[0]
+        assert B == sp["input_ids"].shape[0] and fn["input_ids"].shape[0] == 3 * B
+        # positives are not sampled: identical tensors
+        assert torch.equal(fp["input_ids"], sp["input_ids"]) and torch.equal(fp["labels"], sp["labels"])
+        assert torch.equal(fn["labels"], sn["labels"])
+        assert fp["labels"].tolist() == [[TRUE_ID, EOS_ID]] * B and fn["labels"].tolist() == [[FALSE_ID, EOS_ID]] * (3 * B)
+        assert fn["input_ids"].dtype == torch.int64
+        # every negative row is format(q, d) for a d of that query's list, three distinct per item, padded with 0
+        for b in range(B):
+            item = bi * 4 + b
+            qid = fast.pairs[item][0]
+            allowed = {tuple(tok([format_pair(queries[qid], docs[d])])["input_ids"][0].tolist()) for d in fast.neg_idx[item]}
+            rows = set()
+            for r in fn["input_ids"][3 * b:3 * b + 3]:
+                ids = r.tolist()
+                while ids[-1] == PAD_ID:
+                    ids.pop()
+                assert tuple(ids) in allowed
+                rows.add(tuple(ids))
+            assert len(rows) == 3
+        assert (fn["input_ids"] != PAD_ID).sum(1).max() == fn["input_ids"].shape[1]      # padded to the longest only
+        n_items += B
+    assert n_items == 23
+
+
+def test_batch_loader_shards_like_the_distributed_sampler(dataset):
+    path, corpus, tok, store_dir = dataset
+    dm = module(path, corpus, tok, token_store=store_dir)
+    whole = [p["input_ids"] for p, _ in dm.train_dataloader()]
+    rows = torch.cat([torch.nn.functional.pad(t, (0, 200 - t.shape[1])) for t in whole])
+    for rank in (0, 1):
+        part = [p["input_ids"] for p, _ in dm.train_dataloader(rank=rank, world_size=2)]
+        got = torch.cat([torch.nn.functional.pad(t, (0, 200 - t.shape[1])) for t in part])
+        assert torch.equal(got, rows[rank:22:2])      # 23 items: the odd one out is dropped so that ranks stay in step
+
+
+class _Trainer:
+    def __init__(self, loader):
+        self.train_dataloader = loader
+
+
+class _Module:
+    difficulty = 0.9
+
+
+def test_pace_reaches_the_sampler_only_when_asked(dataset):
+    """ChangeDifficulty writes the dataset's pace (``lceT5.py:77-80``).  With propagate_pace the hardest negatives
+    dominate the next batch; without it the loader keeps sampling at the initial pace, as the reference's workers do."""
+    path, corpus, tok, store_dir = dataset
+    mean_rank = {}
+    for flag in (True, False):
+        dm = module(path, corpus, tok, token_store=store_dir, propagate_pace=flag, seed=2)
+        loader = dm.train_dataloader()
+        loader.prefetch = 0
+        ranks = []
+        it = iter(loader)
+        next(it)                                            # iterator created at the initial pace 0.3466
+        ChangeDifficulty().on_train_batch_start(_Trainer(loader), _Module(), None, 1)
+        assert dm.dataset.weight == pytest.approx(0.9)
+        store = loader.store
+        for _p, n in it:
+            for b, row in enumerate(n["input_ids"]):
+                ids = row[row != PAD_ID].numpy().astype(np.int32)
+                item_rows = None
+                for item in range(len(dm.pairs)):           # find which list position this document has
+                    for pos, d in enumerate(dm.neg_idx[item]):
+                        seq = store.sequence(dm.pairs[item][0], d)
+                        if seq.size == ids.size and (seq == ids).all():
+                            item_rows = pos
+                            break
+                    if item_rows is not None:
+                        break
+                ranks.append(item_rows)
+        mean_rank[flag] = float(np.mean(ranks))
+    assert mean_rank[True] > 30 and mean_rank[False] < 20      # 40-long lists: pace .9 -> ~35, pace .35 -> ~13.5
+
+
+def test_shared_pace_is_visible_to_worker_processes(dataset):
+    path, corpus, tok, _store_dir = dataset
+    dm = LCEDataModule(path, corpus, tok, batch_size=4, n=3, var=0.01, init_weight=0.2, num_workers=1, propagate_pace=True)
+    dm.setup()
+    ds = dm.dataset
+    assert ds.weight == pytest.approx(0.2)
+    ds.weight = 0.75
+    assert ds.weight == pytest.approx(0.75)
+
+    class Probe(torch.utils.data.Dataset):
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return torch.tensor(ds.weight)
+    ds.weight = 0.6
+    seen = [float(x) for x in torch.utils.data.DataLoader(Probe(), batch_size=1, num_workers=1)]
+    assert seen == pytest.approx([0.6, 0.6])
