@@ -155,6 +155,15 @@ int paced_lce_group(const float* pce, const float* nce, float* ce, int R, int n,
  * w[i] = loss[i] <= eta ? loss[i]/eta : 0;
  * stats = { mean(w), mean(w*loss), d mean(w*loss) / d eta, mean(loss) }.  eta is read on the device. */
 int paced_lce_weights(const float* loss, const float* eta, float* w, float* stats, int R, void* stream);
+/* Threshold weights of pacednegatives/weights.py, vectorised (the reference loops over the batch on the host), with
+ * their slope in eta (dw may be NULL):
+ *   form 0 = LCEWeights (weights.py:47-78):  w = l <= eta ? l/eta     : l*mask*eta
+ *   form 1 = EtaWeights (weights.py:10-45):  w = l <= eta ? 1 - l/eta : l*mask*eta */
+int paced_eta_weights(const float* loss, const float* eta, float mask, int form, float* w, float* dw, int R, void* stream);
+/* Meta objective of the eta-bound pace schedule, old/eta_bound.py:73-78: ce = (pce+nce)/2, v = EtaWeights(ce),
+ * J = mean(pce*v) + mean(nce*v) - sum(v).  v[R] receives the weights;
+ * out = { J, dJ/d eta, mean(v), mean(ce < eta) (the success rate of old/eta_bound.py:57-58) }. */
+int paced_eta_bound_meta(const float* pce, const float* nce, const float* eta, float mask, float* v, float* out, int R, void* stream);
 
 /* ---- transformers.AdamW as built at lceT5.py:171-172 (betas .9/.999, eps 1e-6, wd 0) ------------
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= step_size * m/(sqrt(v)+eps); p -= decay*p;

@@ -294,6 +294,49 @@ __global__ void __launch_bounds__(256) lce_weights_kernel(const float* __restric
     }
 }
 
+// Threshold weights of pacednegatives/weights.py with the slope in eta next to them:
+//   form 0 (LCEWeights, :47-78):  w = l <= eta ? l / eta     : l * mask * eta
+//   form 1 (EtaWeights, :10-45):  w = l <= eta ? 1 - l / eta : l * mask * eta
+__device__ __forceinline__ void eta_weight(float l, float eta, float mask, int form, float& w, float& dw) {
+    if (l > eta) { w = l * mask * eta; dw = l * mask; }
+    else if (form == 0) { w = l / eta; dw = -l / (eta * eta); }
+    else { w = 1.f - l / eta; dw = l / (eta * eta); }
+}
+__global__ void eta_weights_kernel(const float* __restrict__ loss, const float* __restrict__ eta_p, float mask, int form,
+                                   float* __restrict__ w, float* __restrict__ dw, int R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    float wi, di;
+    eta_weight(loss[i], eta_p[0], mask, form, wi, di);
+    w[i] = wi;
+    if (dw) dw[i] = di;
+}
+// Meta objective of the eta-bound schedule (old/eta_bound.py:73-78): ce = (pce + nce) / 2, v = EtaWeights(ce),
+// J = mean(pce v) + mean(nce v) - sum(v).  out = { J, dJ/d eta, mean(v), mean(ce < eta) }.
+__global__ void __launch_bounds__(256) eta_bound_meta_kernel(const float* __restrict__ pce, const float* __restrict__ nce,
+                                                            const float* __restrict__ eta_p, float mask, float* __restrict__ v,
+                                                            float* __restrict__ out, int R) {
+    __shared__ float sh[4][4];
+    const float eta = eta_p[0], inv = 1.f / (float)R;
+    float sj = 0.f, sg = 0.f, sv = 0.f, ss = 0.f;
+    for (int i = threadIdx.x; i < R; i += 256) {
+        const float p = pce[i], n = nce[i], ce = (p + n) * 0.5f;
+        float vi, di;
+        eta_weight(ce, eta, mask, 1, vi, di);
+        v[i] = vi;
+        const float coef = (p + n) * inv - 1.f;          // dJ / dv_i
+        sj += coef * vi; sg += coef * di; sv += vi; ss += ce < eta ? 1.f : 0.f;
+    }
+    sj = wave_sum(sj); sg = wave_sum(sg); sv = wave_sum(sv); ss = wave_sum(ss);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { sh[wv][0] = sj; sh[wv][1] = sg; sh[wv][2] = sv; sh[wv][3] = ss; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        out[threadIdx.x] = threadIdx.x < 2 ? t : t * inv;
+    }
+}
+
 // ------------------------------------------------------------------- relative-position-bias tables
 // tbl[h][i] = rel_bias[bucket[i]][h] for i in [0, L): the additive bias as a function of
 // (key - query) only; the bucket of each offset is computed on the host.
@@ -446,6 +489,18 @@ extern "C" int paced_lce_group(const float* pce, const float* nce, float* ce, in
     return PACED_OK;
 }
 
+extern "C" int paced_eta_weights(const float* loss, const float* eta, float mask, int form, float* w, float* dw, int R, void* stream) {
+    PACED_CHECK_ARG(loss && eta && w && R > 0 && (form == 0 || form == 1), "paced_eta_weights: bad arguments");
+    hipLaunchKernelGGL(eta_weights_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, loss, eta, mask, form, w, dw, R);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+extern "C" int paced_eta_bound_meta(const float* pce, const float* nce, const float* eta, float mask, float* v, float* out, int R, void* stream) {
+    PACED_CHECK_ARG(pce && nce && eta && v && out && R > 0, "paced_eta_bound_meta: bad arguments");
+    hipLaunchKernelGGL(eta_bound_meta_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pce, nce, eta, mask, v, out, R);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
 extern "C" int paced_lce_weights(const float* loss, const float* eta, float* w, float* stats, int R, void* stream) {
     PACED_CHECK_ARG(loss && eta && w && stats && R > 0, "paced_lce_weights: bad arguments");
     hipLaunchKernelGGL(lce_weights_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss, eta, w, stats, R);

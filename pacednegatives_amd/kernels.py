@@ -321,6 +321,27 @@ def lce_weights(loss, eta, w, stats):
     return w
 
 
+def eta_weights(loss, eta, w, dw=None, *, mask=0.0, form=1):
+    """Threshold weights of pacednegatives/weights.py (form 0 = LCEWeights, 1 = EtaWeights) and their slope in eta."""
+    lib = _lib.load()
+    _chk(loss, F32, "loss"); _chk(eta, F32, "eta"); _chk(w, F32, "w"); _chk(dw, F32, "dw")
+    R = loss.numel()
+    if w.numel() != R or (dw is not None and dw.numel() != R) or eta.numel() < 1:
+        raise ValueError("eta_weights: w and dw must have the length of loss")
+    _lib.check(lib.paced_eta_weights(_p(loss), _p(eta), float(mask), int(form), _p(w), _p(dw), R, _stream()), "paced_eta_weights")
+
+
+def eta_bound_meta(pce, nce, eta, v, out, *, mask=0.0):
+    """Meta objective of the eta-bound schedule; out = [J, dJ/d eta, mean v, success rate]."""
+    lib = _lib.load()
+    for t, n in ((pce, "pce"), (nce, "nce"), (eta, "eta"), (v, "v"), (out, "out")):
+        _chk(t, F32, n)
+    R = pce.numel()
+    if nce.numel() != R or v.numel() != R or out.numel() < 4:
+        raise ValueError("eta_bound_meta: pce, nce and v must have one length and out four slots")
+    _lib.check(lib.paced_eta_bound_meta(_p(pce), _p(nce), _p(eta), float(mask), _p(v), _p(out), R, _stream()), "paced_eta_bound_meta")
+
+
 def adamw(p, g, m, v, p_bf16, *, beta1=0.9, beta2=0.999, eps=1e-6, step_size, decay=0.0, grad_scale=1.0):
     lib = _lib.load()
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
