@@ -81,6 +81,7 @@ def run_train(args, rank, world, device):
     # one instrumented step: per-launch HIP events around the contraction kernel
     roof = None
     K.PROFILE = []
+    model.overlap_forwards = False      # per-launch durations: no second stream sharing the GPU with the timed kernel
     model.training_step(batch, args.warmup + args.steps)
     torch.cuda.synchronize()
     prof, K.PROFILE = K.PROFILE, None

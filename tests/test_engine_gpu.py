@@ -321,6 +321,36 @@ def test_dropout_step_runs_and_is_seed_deterministic():
     assert torch.equal(rows[0], rows[1])
 
 
+def test_side_stream_forwards_give_the_same_steps():
+    """The no-grad forwards of a step run on a second stream beside the forwards that keep state (from the second
+    step on); every logged quantity must match the in-order schedule.  Weight gradients are accumulated with fp32
+    atomics, so later steps agree to rounding, not bit for bit."""
+    from pacednegatives_amd.lceT5 import LCEModel
+    from pacednegatives_amd.synthetic import token_batch
+    runs = []
+    for overlap in (False, True):
+        hp = {"model_name": "t5-tiny", "total_steps": 10, "eta": 0.9, "batch_size": 4, "lr": 1e-3, "meta_lr": 1e-2, "n": 3,
+              "warmup_steps": 0, "use_mean": False, "ignore_index": -100, "dropout": 0.1, "dropout_seed": 5,
+              "overlap_forwards": overlap}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = LCEModel(hp)
+        model.model.params.load_hf(init_params(RTINY, 0))
+        assert model.overlap_forwards is overlap
+        steps = []
+        for it in range(4):
+            out = model.training_step(token_batch(4, 3, 48, TINY.vocab_size, seed=100 + it), it)
+            steps.append((out["loss_rows"].cpu(), out["main_loss_rows"].cpu(), out["weights"].cpu(), model.difficulty))
+        assert (model._side_stream is not None) is overlap
+        runs.append(steps)
+    for it, (a, b) in enumerate(zip(*runs)):
+        if it == 0:
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for x, y in zip(a[:3], b[:3]):
+            np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=2e-3, atol=1e-5)
+        assert abs(a[3] - b[3]) < 1e-5
+
+
 def test_save_pretrained_round_trip(tmp_path):
     from pacednegatives_amd.model import T5ForConditionalGenerationHIP
     m, P = make_model(3)
