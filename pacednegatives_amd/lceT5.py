@@ -329,6 +329,7 @@ class LCEModel:
             K.lce_group(pce, nce, loss, nneg, use_mean)
             del states, plog, nlog, pce, nce
         early = self._forward_pair(p, n, save=True, call=1) if overlap else None        # the forwards of (d)
+        self.model.engine.dw_stream = self._side_stream if overlap else None             # and the weight gradients of its backward
         if overlap:
             main.wait_stream(self._side_stream)
             loss.record_stream(main)

@@ -130,6 +130,7 @@ class T5Engine:
         self.device = params.device
         self._bucket_cache: Dict[int, torch.Tensor] = {}
         self.force_kv_projection = False      # tests: take the explicit K/V projection path of the cross-attention
+        self.dw_stream = None                  # when set: weight-gradient products of backward() run on this stream
         self.ffn_bit_mask = os.environ.get("PACED_FFN_BITMASK", "1") != "0"   # encoder FFN backward masks by saved sign bits
         self._bucket_dec = torch.tensor([0, 1], dtype=torch.int32, device=self.device)   # offsets 0 and -1 (HF:244-249)
         dec_b = relative_position_bucket(torch.tensor([0, -1]), False, dims.num_buckets, dims.max_distance)
@@ -162,7 +163,20 @@ class T5Engine:
         g = self.params.grad(name)
         if rows is not None:
             g = g[rows]
-        K.gemm(dy, x, g, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)   # 0: library picks the split
+        side = self.dw_stream
+        if side is None:
+            K.gemm(dy, x, g, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)   # 0: library picks the split
+            return
+        # Nothing in the backward chain reads a weight gradient, so the product runs on a second stream and its
+        # workgroups fill the CUs that the chain's kernel tails leave idle.  Both operands are complete once the
+        # work enqueued on the calling stream so far has run; they are never written again, and record_stream keeps
+        # their memory from being handed out again before the product has read it.
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            K.gemm(dy, x, g, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)
+        dy.record_stream(side)
+        x.record_stream(side)
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids: torch.Tensor, labels: torch.Tensor, *, save: bool, drop_p: float = 0.0, seed: int = 0,
@@ -454,5 +468,7 @@ class T5Engine:
             sv.__dict__.clear()
         K.embedding_bwd(st.ids, dh, P.grad("shared"), drop_p=p, drop_seed=self._seed(st, _SITE_EMB))
         K.relbias_table_bwd(dbias_tbl, st.bucket_enc, P.grad("enc.rel_bias"))
+        if self.dw_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.dw_stream)
         st.enc_layers.clear()
         st.dec_layers.clear()
