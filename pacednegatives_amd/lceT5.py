@@ -231,7 +231,7 @@ class LCEModel:
         self.share_forward = bool(self.hparams.get("share_forward", False))
         # run the no-grad forwards of a step on a second stream beside the forwards that keep state
         self.overlap_forwards = bool(self.hparams.get("overlap_forwards", os.environ.get("PACED_OVERLAP_FORWARDS", "1") != "0"))
-        self._side_stream = None
+        self._side_stream = self._aux_stream = None
         self.difficulty = float(self.weights.eta.item())
         self.global_step = 0
         self.logged = OrderedDict()
@@ -279,7 +279,7 @@ class LCEModel:
         return ce
 
     # ---- the step
-    def _forward_pair(self, p, n, save, call):
+    def _forward_pair(self, p, n, save, call, after_encoder=None):
         """Run the positive and negative batches; one packed call when their lengths agree."""
         eng = self.model.engine
         seed = (self._base_seed * 0x9E3779B1 + self.global_step * 8 + call) & 0xFFFFFFFF
@@ -287,10 +287,10 @@ class LCEModel:
         if p["input_ids"].shape[1] == n["input_ids"].shape[1]:
             ids = torch.cat([p["input_ids"].to(self.device), n["input_ids"].to(self.device)], 0)
             lab = torch.cat([p["labels"].to(self.device), n["labels"].to(self.device)], 0)
-            st = eng.forward(ids, lab, save=save, drop_p=self.dropout, seed=seed)
+            st = eng.forward(ids, lab, save=save, drop_p=self.dropout, seed=seed, after_encoder=after_encoder)
             return [st], st.logits[:2 * B], st.logits[2 * B:]
         sp = eng.forward(p["input_ids"], p["labels"], save=save, drop_p=self.dropout, seed=seed)
-        sn = eng.forward(n["input_ids"], n["labels"], save=save, drop_p=self.dropout, seed=seed ^ 0x55555555)
+        sn = eng.forward(n["input_ids"], n["labels"], save=save, drop_p=self.dropout, seed=seed ^ 0x55555555, after_encoder=after_encoder)
         return [sp, sn], sp.logits, sn.logits
 
     def training_step(self, batch, batch_nb):
@@ -308,66 +308,84 @@ class LCEModel:
         nlab = n["labels"].to(self.device, torch.int64).contiguous().view(-1)
         ign = int(hp.ignore_index)
 
-        # (a) no-grad forwards and the LCE rows                                             :131-135
-        # The forwards of (a) and of (d) read the same parameters and neither depends on eta, so (a) runs on a side
-        # stream next to (d): workgroups of one fill the CUs the other's kernel tails and two-token decoder kernels
-        # leave idle (59.5 against 64.4 ms for the pair at the benchmark shape; same values either way).  The first
-        # step runs them in order, so that everything cached on first use exists before two streams read it.
+        # Nothing in (d) -- the forwards that keep state, the main loss, its backward -- depends on (a) or on eta, and
+        # (a) only feeds eta's meta update and the log.  So (a) runs on a second stream, started when (d)'s encoder
+        # forward has been enqueued: its large kernels then fill the GPU while (d) is in its two-token decoder forward
+        # and backward, and kernel tails on both sides.  The weight gradients of the backward go to a third stream
+        # for the same reason.  Values are those of the in-order schedule.  The first step runs in order, so that
+        # everything cached on first use exists before two streams read it.
         overlap = self.overlap_forwards and self.global_step > 0 and self.device.type == "cuda"
-        main = torch.cuda.current_stream() if overlap else None
-        if overlap:
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
-            self._side_stream.wait_stream(main)
-        with (torch.cuda.stream(self._side_stream) if overlap else contextlib.nullcontext()):
-            states, plog, nlog = self._forward_pair(p, n, save=False, call=0)
-            pce = torch.empty(2 * B, dtype=F32, device=self.device)
-            nce = torch.empty(2 * B * nneg, dtype=F32, device=self.device)
-            K.cross_entropy(plog, plab, pce, None, ignore_index=ign)
-            K.cross_entropy(nlog, nlab, nce, None, ignore_index=ign)
-            loss = torch.empty(2 * B, dtype=F32, device=self.device)
-            K.lce_group(pce, nce, loss, nneg, use_mean)
-            del states, plog, nlog, pce, nce
-        early = self._forward_pair(p, n, save=True, call=1) if overlap else None        # the forwards of (d)
-        self.model.engine.dw_stream = self._side_stream if overlap else None             # and the weight gradients of its backward
-        if overlap:
-            main.wait_stream(self._side_stream)
-            loss.record_stream(main)
-
-        # (b) weights and the meta update of eta                                            :137-143
-        weights = self.weights(loss)
-        meta_opt_grad = self.weights.eta_grad
-        stats = self.weights.stats.clone()
-        parallel.allreduce_sum_(meta_opt_grad)                  # sum over ranks; averaged by grad_scale below
-        meta_opt.step(grad_scale=1.0 / world)
-        meta_scheduler.step()
-
-        # (d) forwards with state, loss, backward, main update                              :149-157
         R = 2 * B
         g_pos = 1.0 / R
         g_neg = (1.0 / R) * ((1.0 / nneg) if use_mean else 1.0)
         if self.share_forward and self.dropout == 0.0:
             raise NotImplementedError("share_forward is reserved for a later round")
-        states, plog, nlog = early if early is not None else self._forward_pair(p, n, save=True, call=1)
-        V = plog.shape[1]
-        pce2 = torch.empty(2 * B, dtype=F32, device=self.device)
-        nce2 = torch.empty(2 * B * nneg, dtype=F32, device=self.device)
-        if len(states) == 1:
-            dl = torch.empty(states[0].logits.shape, dtype=BF16, device=self.device)
-            K.cross_entropy(plog, plab, pce2, dl[:2 * B], ignore_index=ign, gscale=g_pos)
-            K.cross_entropy(nlog, nlab, nce2, dl[2 * B:], ignore_index=ign, gscale=g_neg)
-            states[0].logits = None
-            self.model.engine.backward(states[0], dl)
+
+        def no_grad_rows():
+            """(a) no-grad forwards and the LCE rows                                        :131-135"""
+            states, plog, nlog = self._forward_pair(p, n, save=False, call=0)
+            pce = torch.empty(2 * B, dtype=F32, device=self.device)
+            nce = torch.empty(2 * B * nneg, dtype=F32, device=self.device)
+            K.cross_entropy(plog, plab, pce, None, ignore_index=ign)
+            K.cross_entropy(nlog, nlab, nce, None, ignore_index=ign)
+            rows = torch.empty(2 * B, dtype=F32, device=self.device)
+            K.lce_group(pce, nce, rows, nneg, use_mean)
+            return rows
+
+        def meta_update(rows):
+            """(b) weights and the meta update of eta                                       :137-143"""
+            w = self.weights(rows)
+            st_ = self.weights.stats.clone()
+            parallel.allreduce_sum_(self.weights.eta_grad)          # sum over ranks; averaged by grad_scale below
+            meta_opt.step(grad_scale=1.0 / world)
+            meta_scheduler.step()
+            return w, st_
+
+        def main_backward(after_encoder=None):
+            """(d) forwards with state, loss, backward                                      :149-155"""
+            states, plog, nlog = self._forward_pair(p, n, save=True, call=1, after_encoder=after_encoder)
+            pce2 = torch.empty(2 * B, dtype=F32, device=self.device)
+            nce2 = torch.empty(2 * B * nneg, dtype=F32, device=self.device)
+            if len(states) == 1:
+                dl = torch.empty(states[0].logits.shape, dtype=BF16, device=self.device)
+                K.cross_entropy(plog, plab, pce2, dl[:2 * B], ignore_index=ign, gscale=g_pos)
+                K.cross_entropy(nlog, nlab, nce2, dl[2 * B:], ignore_index=ign, gscale=g_neg)
+                states[0].logits = None
+                self.model.engine.backward(states[0], dl)
+            else:
+                dlp = torch.empty(plog.shape, dtype=BF16, device=self.device)
+                K.cross_entropy(plog, plab, pce2, dlp, ignore_index=ign, gscale=g_pos)
+                self.model.engine.backward(states[0], dlp)
+                dln = torch.empty(nlog.shape, dtype=BF16, device=self.device)
+                K.cross_entropy(nlog, nlab, nce2, dln, ignore_index=ign, gscale=g_neg)
+                self.model.engine.backward(states[1], dln)
+            rows = torch.empty(2 * B, dtype=F32, device=self.device)
+            K.lce_group(pce2, nce2, rows, nneg, use_mean)
+            return rows
+
+        if not overlap:
+            self.model.engine.dw_stream = None
+            loss = no_grad_rows()
+            weights, stats = meta_update(loss)
+            main_loss = main_backward()
         else:
-            dlp = torch.empty(plog.shape, dtype=BF16, device=self.device)
-            K.cross_entropy(plog, plab, pce2, dlp, ignore_index=ign, gscale=g_pos)
-            self.model.engine.backward(states[0], dlp)
-            dln = torch.empty(nlog.shape, dtype=BF16, device=self.device)
-            K.cross_entropy(nlog, nlab, nce2, dln, ignore_index=ign, gscale=g_neg)
-            self.model.engine.backward(states[1], dln)
-        main_loss = torch.empty(2 * B, dtype=F32, device=self.device)
-        K.lce_group(pce2, nce2, main_loss, nneg, use_mean)
-        del states, plog, nlog
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+                self._aux_stream = torch.cuda.Stream(device=self.device)
+            aux, box = self._aux_stream, {}
+
+            def start_no_grad_forwards():
+                aux.wait_stream(main)                   # parameters of the last update, and (d)'s encoder forward
+                with torch.cuda.stream(aux):
+                    box["loss"] = no_grad_rows()
+            self.model.engine.dw_stream = self._side_stream
+            main_loss = main_backward(after_encoder=start_no_grad_forwards)
+            main.wait_stream(aux)
+            loss = box["loss"]
+            loss.record_stream(main)
+            weights, stats = meta_update(loss)
+        # main update                                                                        :156-157
         parallel.allreduce_sum_(self.model.params.g32)          # one all-reduce over the flat fp32 gradient buffer
         opt.step(grad_scale=1.0 / world)
         scheduler.step()

@@ -180,7 +180,9 @@ class T5Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids: torch.Tensor, labels: torch.Tensor, *, save: bool, drop_p: float = 0.0, seed: int = 0,
-                want_logits: bool = True) -> ForwardState:
+                want_logits: bool = True, after_encoder=None) -> ForwardState:
+        """``after_encoder`` (optional callable) runs once the encoder's kernels are enqueued, before the decoder's
+        small kernels: the place to start independent work on another stream."""
         dims, P = self.dims, self.params
         if input_ids.dim() != 2 or labels.dim() != 2 or labels.shape[1] != 2 or labels.shape[0] != input_ids.shape[0]:
             raise ValueError(f"expected input_ids [N,S] and labels [N,2], got {tuple(input_ids.shape)} and {tuple(labels.shape)}")
@@ -237,6 +239,8 @@ class T5Engine:
         rstd_ef = torch.empty(M, dtype=F32, device=self.device)
         K.rmsnorm_fwd(h, P.w("enc.final_ln"), enc, rstd_ef, eps=dims.eps, drop_p=p, drop_seed=self._seed(st, _SITE_ENC_FINAL))
         st.enc_out = enc
+        if after_encoder is not None:
+            after_encoder()
         if save:
             st.h_last, st.rstd_ef = h, rstd_ef
 
