@@ -319,7 +319,7 @@ class LCEModel:
         g_pos = 1.0 / R
         g_neg = (1.0 / R) * ((1.0 / nneg) if use_mean else 1.0)
         if self.share_forward and self.dropout == 0.0:
-            raise NotImplementedError("share_forward is reserved for a later round")
+            raise NotImplementedError("share_forward (one forward serving both passes when dropout is off) is not implemented")
 
         def no_grad_rows():
             """(a) no-grad forwards and the LCE rows                                        :131-135"""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end measurement on one GPU box: GPU tests, smoke, HBM-traffic counters (two separate --pmc passes), kernel trace,
+# Full measurement on one GPU box: GPU tests, smoke, HBM-traffic counters (two separate --pmc passes), kernel trace,
 # and the default bench line.  Every GPU step runs under its own time limit; the script stops at the first failure.
 set -o pipefail
 mkdir -p gpurun_out/final
