@@ -321,7 +321,8 @@ def test_dropout_step_runs_and_is_seed_deterministic():
     assert torch.equal(rows[0], rows[1])
 
 
-def test_side_stream_forwards_give_the_same_steps():
+@pytest.mark.parametrize("neg_len", [48, 61])
+def test_side_stream_forwards_give_the_same_steps(neg_len):
     """The no-grad forwards of a step run on a second stream beside the forwards that keep state (from the second
     step on); every logged quantity must match the in-order schedule.  Weight gradients are accumulated with fp32
     atomics, so later steps agree to rounding, not bit for bit."""
@@ -339,7 +340,10 @@ def test_side_stream_forwards_give_the_same_steps():
         assert model.overlap_forwards is overlap
         steps = []
         for it in range(4):
-            out = model.training_step(token_batch(4, 3, 48, TINY.vocab_size, seed=100 + it), it)
+            pos, neg = token_batch(4, 3, 48, TINY.vocab_size, seed=100 + it)
+            if neg_len != 48:           # negatives of another length: positives and negatives go through two engine calls
+                neg = {"input_ids": token_batch(4, 3, neg_len, TINY.vocab_size, seed=200 + it)[1]["input_ids"], "labels": neg["labels"]}
+            out = model.training_step((pos, neg), it)
             steps.append((out["loss_rows"].cpu(), out["main_loss_rows"].cpu(), out["weights"].cpu(), model.difficulty))
         assert (model._side_stream is not None) is overlap
         runs.append(steps)
