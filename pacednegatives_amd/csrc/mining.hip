@@ -48,15 +48,30 @@ __global__ void __launch_bounds__(256) topk_select_kernel(unsigned long long* ca
             if ((key & mask) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int cum = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (cum + hist[b] >= need) break;
-                cum += hist[b];
+        if (threadIdx.x < 64) {
+            // bin of the key of rank `need` from the top: lane l owns bins 4l .. 4l+3; a suffix scan over the lanes
+            // finds the one lane whose bins straddle the rank (a serial walk over 256 bins by one thread was most
+            // of this kernel's time)
+            const int l = threadIdx.x;
+            const unsigned int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            const unsigned int own = h0 + h1 + h2 + h3;
+            unsigned int suf = own;                                  // sum over lanes >= l
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int up = (unsigned int)__shfl_down((int)suf, o, 64);
+                if (l + o < 64) suf += up;
             }
-            sh_bin = (unsigned int)b;
-            sh_need = need - cum;
+            const unsigned int above = suf - own;                    // keys in higher bins than this lane's
+            if (l == 0) { sh_bin = 0; sh_need = need - (suf - h0); }  // rank beyond every bin above 0 (cannot happen: need <= matching keys)
+            if (above < need && need <= suf) {
+                unsigned int cum = above;
+                int b = 4 * l + 3;
+                if (cum + h3 < need) { cum += h3; b = 4 * l + 2;
+                    if (cum + h2 < need) { cum += h2; b = 4 * l + 1;
+                        if (cum + h1 < need) { cum += h1; b = 4 * l; } } }
+                sh_bin = (unsigned int)b;
+                sh_need = need - cum;
+            }
         }
         __syncthreads();
         prefix |= (unsigned long long)sh_bin << shift;
