@@ -254,20 +254,7 @@ template <class Cfg, int EPI>
 __device__ __forceinline__ void epilogue(const GemmParams& p, void* Cb, int m0, int n0, int wm, int wn, int lane,
                                          f32x4 (&acc)[Cfg::MI][Cfg::NJ]) {
     constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
-    if (EPI == EPI_TOPK_DENSE || EPI == EPI_TOPK_FILTER) {
-        // The filter's thresholds and its slot counter go through inline-asm statements that wait for themselves:
-        // a register-destination load or returning atomic the compiler can see makes it put `s_waitcnt vmcnt(0)`
-        // ahead of every LDS read of the kernel, which drains the K loop's LDS-DMA ring once per K step.
-        float thr[NJ];
-        if (EPI == EPI_TOPK_FILTER) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const float* src = p.tk_thr + min(n0 + Cfg::noff(wn, j) + (lane & 15), p.N - 1);
-                asm volatile("global_load_dword %0, %1, off" : "=v"(thr[j]) : "v"(src) : "memory");
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(thr[j]) :: "memory");
-        }
+    if (EPI == EPI_TOPK_DENSE) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = n0 + Cfg::noff(wn, j) + (lane & 15);
@@ -278,18 +265,68 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, void* Cb, int m0, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + Cfg::moff(wm, i) + (lane >> 4) * 4 + r;
-                    if (m >= p.M) continue;
-                    const float sc = acc[i][j][r];
-                    if (EPI == EPI_TOPK_DENSE) {
-                        cand[m] = topk_key(sc, p.tk_row_base + (unsigned int)m);
-                    } else if (sc >= thr[j]) {
-                        unsigned int pos;
-                        const unsigned int one = 1u;
-                        unsigned int* slot = p.tk_cnt + n;
-                        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(pos) : "v"(slot), "v"(one) : "memory");
-                        if (pos < (unsigned int)p.tk_cap) cand[pos] = topk_key(sc, p.tk_row_base + (unsigned int)m);
+                    if (m < p.M) cand[m] = topk_key(acc[i][j][r], p.tk_row_base + (unsigned int)m);
+                }
+        }
+        return;
+    }
+    if (EPI == EPI_TOPK_FILTER) {
+        // The thresholds and the slot counters go through inline-asm statements with their own waits: a
+        // register-destination load or returning atomic the compiler can see makes it put `s_waitcnt vmcnt(0)`
+        // ahead of every LDS read of the kernel, which drains the K loop's LDS-DMA ring once per K step.
+        // A lane first marks which of its MI x 4 scores per column pass (one bit each), then reserves all the slots
+        // of a column with ONE returning atomic; the NJ atomics of a lane are in flight together and waited for
+        // once.  (An atomic per passing score, each waited for, cost a memory round trip per score: in the early
+        // chunks of a sweep, where ~0.2 % of the scores pass, that was as long as the item's whole K loop.)
+        static_assert(MI * 4 <= 32, "one pass bit per score and column");
+        float thr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float* src = p.tk_thr + min(n0 + Cfg::noff(wn, j) + (lane & 15), p.N - 1);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(thr[j]) : "v"(src) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(thr[j]) :: "memory");
+        unsigned int pass[NJ], pos[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + Cfg::noff(wn, j) + (lane & 15);
+            unsigned int bits = 0;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + Cfg::moff(wm, i) + (lane >> 4) * 4 + r;
+                    bits |= (m < p.M && acc[i][j][r] >= thr[j] ? 1u : 0u) << (i * 4 + r);
+                }
+            pass[j] = n < p.N ? bits : 0u;
+            pos[j] = 0;
+            if (pass[j]) {
+                const unsigned int count = __popc(pass[j]);
+                unsigned int* slot = p.tk_cnt + n;
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(pos[j]) : "v"(slot), "v"(count) : "memory");
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pos[j]) :: "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (__ballot(pass[j] != 0) == 0) continue;               // nobody in the wave has a candidate in this column group
+            const int n = n0 + Cfg::noff(wn, j) + (lane & 15);
+            unsigned long long* cand = p.tk_cand + (size_t)min(n, p.N - 1) * p.tk_cap;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (__ballot(((pass[j] >> (i * 4)) & 15u) != 0) == 0) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bit = i * 4 + r;
+                    if ((pass[j] >> bit) & 1u) {
+                        const unsigned int at = pos[j] + __popc(pass[j] & ((1u << bit) - 1u));
+                        const int m = m0 + Cfg::moff(wm, i) + (lane >> 4) * 4 + r;
+                        if (at < (unsigned int)p.tk_cap) cand[at] = topk_key(acc[i][j][r], p.tk_row_base + (unsigned int)m);
                     }
                 }
+            }
         }
         return;
     }
