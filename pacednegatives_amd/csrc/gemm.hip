@@ -286,7 +286,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, void* Cb, int m0, 
             asm volatile("global_load_dword %0, %1, off" : "=v"(thr[j]) : "v"(src) : "memory");
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(thr[j]) :: "memory");
+        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0) ; hidden-load wait" : "+v"(thr[j]) :: "memory");
         unsigned int pass[NJ], pos[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -308,7 +308,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, void* Cb, int m0, 
             }
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pos[j]) :: "memory");
+        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0) ; hidden-load wait" : "+v"(pos[j]) :: "memory");
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (__ballot(pass[j] != 0) == 0) continue;               // nobody in the wave has a candidate in this column group
@@ -530,7 +530,7 @@ __device__ __forceinline__ int ring_wrap(int x) { return x >= 10 ? x - 10 : x; }
 // Edge tiles clamp the load addresses into the matrix, predicate the stores and wait for each batch of eight whole.
 template <class T>
 __device__ __forceinline__ void wait_hidden_load(int n, T& x) {
-#define PACED_WAIT_CASE(N, CNT) if (n == N) asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(x) :: "memory");
+#define PACED_WAIT_CASE(N, CNT) if (n == N) asm volatile("s_waitcnt vmcnt(" #CNT ") ; hidden-load wait" : "+v"(x) :: "memory");
     PACED_WAIT_CASE(0, 7) PACED_WAIT_CASE(1, 8) PACED_WAIT_CASE(2, 9) PACED_WAIT_CASE(3, 10)
     PACED_WAIT_CASE(4, 11) PACED_WAIT_CASE(5, 12) PACED_WAIT_CASE(6, 13) PACED_WAIT_CASE(7, 14)
     PACED_WAIT_CASE(8, 14) PACED_WAIT_CASE(9, 13) PACED_WAIT_CASE(10, 12) PACED_WAIT_CASE(11, 11)
@@ -539,7 +539,7 @@ __device__ __forceinline__ void wait_hidden_load(int n, T& x) {
 }
 template <class T>
 __device__ __forceinline__ void wait_hidden_batch(T (&x)[8]) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) :: "memory");
+    asm volatile("s_waitcnt vmcnt(0) ; hidden-load wait" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) :: "memory");
 }
 
 template <int EPI, bool FULL>

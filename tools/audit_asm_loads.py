@@ -4,7 +4,7 @@
 The compiler treats the destination of an asm load as written when the statement ends, so it is free to copy,
 spill or reuse those registers before the data has landed.  This script walks the .s text in program order and
 reports every instruction that touches the destination registers of an asm `global_load_*` between the load and
-the hand-written `s_waitcnt vmcnt(N)` that releases it (a counted wait releases the oldest pending load, vmcnt(0)
+the hand-written `s_waitcnt vmcnt(N) ; hidden-load wait` that releases it (a counted wait releases the oldest pending load, vmcnt(0)
 all of them), and checks every counted wait: N must not exceed the number of vector-memory instructions issued after
 the load it releases, or the wait could return before the data has landed.
 
@@ -55,7 +55,7 @@ def main(path):
             pending.append((ln, regs_of(dst), vm_seq))
             loads += 1
             continue
-        elif in_asm and code.startswith("s_waitcnt vmcnt("):
+        elif in_asm and code.startswith("s_waitcnt vmcnt(") and "hidden-load wait" in s:
             n = int(code[len("s_waitcnt vmcnt("):].split(")")[0])
             if n == 0:
                 pending = []
