@@ -573,6 +573,24 @@ def test_pool_topk_exact_vs_oracle(Q, Np, D, k):
         assert (i.cpu().numpy()[:, kk:] == -1).all()
 
 
+def test_pool_topk_when_every_row_beats_the_threshold():
+    """Scores that grow with the row index: every row of every chunk passes the filter (the most slot reservations the
+    epilogue can see, lists filled to capacity before each trim), and ties between neighbouring rows exercise the
+    (score desc, row asc) order."""
+    from oracle import mining_ref
+    Q, Np, D, k = 300, 150000, 64, 257
+    q = np.zeros((Q, D), dtype=np.float32)
+    q[:, 0] = 1.0
+    q[::3, 1] = 1.0                                            # a third of the queries sees a different ranking
+    p = np.zeros((Np, D), dtype=np.float32)
+    p[:, 0] = np.arange(Np) // 1024                            # bf16-exact (< 256), constant over runs of 1024 rows: ties
+    p[:, 1] = (np.arange(Np) % 7).astype(np.float32)
+    s, i = K.pool_topk(bf(torch.from_numpy(q)), bf(torch.from_numpy(p)), k)
+    ws, wi = mining_ref.pool_topk(q, p, k)
+    assert np.array_equal(i.cpu().numpy(), wi)
+    assert np.array_equal(s.cpu().numpy(), ws)
+
+
 def test_topk_merge_of_shards():
     from oracle import mining_ref
     rng = np.random.RandomState(4)
