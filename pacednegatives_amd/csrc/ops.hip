@@ -127,6 +127,169 @@ __global__ void __launch_bounds__(ROW_BLOCK) rmsnorm_bwd_kernel(const bf16* __re
     }
 }
 
+// Row-group variant of the backward kernel for d = LPR * PER * 8: LPR lanes share a row, so a wave works on 64 / LPR
+// rows at once, every lane carries PER 16-byte pieces of each operand, and all loads of a row group are issued before
+// the first use.  With one row per wave (above) d = 768 leaves a third of the lanes idle and too few bytes in flight
+// to cover HBM latency: 16-22 % less time on 139264 x 768 (5.4 TB/s with every operand present, cold caches).  The
+// forward kernel gains nothing from the same layout.  Same arithmetic per element as above; only the order of the
+// row sums differs.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// operands stay packed (two bf16 per register) until the element is used
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t bf_pack(float a, float b) {
+    const bf16x2 v = __builtin_convertvector((__attribute__((ext_vector_type(2))) float){a, b}, bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&v);
+}
+// Called inside a loop on loop-invariant packed operands: the compiler would otherwise unpack them to one register per
+// element ahead of the loop and spill.
+template <int N>
+__device__ __forceinline__ void keep_packed(u32x4 (&r)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(r[i][j]));
+}
+
+// DROP: dropout on the norm output (the two final norms only)
+template <int LPR, int PER, bool DROP>
+__global__ void __launch_bounds__(ROW_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
+rmsnorm_bwd_rows_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                                    const bf16* __restrict__ w, const float* __restrict__ rstd,
+                                                                    const bf16* __restrict__ dres, bf16* __restrict__ dx,
+                                                                    bf16* __restrict__ dx2, float* __restrict__ dw,
+                                                                    int M, float out_scale, DropCfg drop, DropCfg drop2) {
+    constexpr int d = LPR * PER * 8, RPW = 64 / LPR;
+    __shared__ float red[4][d];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ll = lane % LPR, sub = lane / LPR;
+    u32x4 wr[PER];
+    float dwacc[PER][8];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        wr[i] = *reinterpret_cast<const u32x4*>(w + (ll + i * LPR) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwacc[i][j] = 0.f;
+    }
+    for (int row0 = (blockIdx.x * 4 + wv) * RPW; row0 < M; row0 += gridDim.x * 4 * RPW) {
+        const int row = row0 + sub;
+        const bool ok = row < M;
+        const int rr = ok ? row : M - 1;
+        const size_t base = (size_t)rr * d;
+        u32x4 dv[PER], xv[PER], rv[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            dv[i] = *reinterpret_cast<const u32x4*>(dy + base + (ll + i * LPR) * 8);
+            xv[i] = *reinterpret_cast<const u32x4*>(x + base + (ll + i * LPR) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            rv[i] = dres ? *reinterpret_cast<const u32x4*>(dres + base + (ll + i * LPR) * 8) : u32x4{0u, 0u, 0u, 0u};
+        const float rs = rstd[rr];
+        const float okf = ok ? out_scale : 0.f;
+        keep_packed(wr);
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            float df[8];
+            if (DROP) drop_factor8(drop, (uint64_t)base + (ll + i * LPR) * 8, df);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t du = dv[i][j >> 1], xu = xv[i][j >> 1], wu = wr[i][j >> 1];
+                const float dyo = ((j & 1) ? bf_hi(du) : bf_lo(du)) * (DROP ? df[j] : 1.f);
+                const float xh = ((j & 1) ? bf_hi(xu) : bf_lo(xu)) * rs;
+                const float g = dyo * ((j & 1) ? bf_hi(wu) : bf_lo(wu)) * out_scale;
+                dot += g * xh;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one piece at a time: the scheduler otherwise unpacks every piece first and spills
+        }
+        dot = row_sum<LPR>(dot) / (float)d;
+        keep_packed(dv);
+        keep_packed(xv);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = ll + i * LPR;
+            float df[8], df2[8], v[8];
+            if (DROP) drop_factor8(drop, (uint64_t)base + c * 8, df);
+            drop_factor8(drop2, (uint64_t)base + c * 8, df2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t du = dv[i][j >> 1], xu = xv[i][j >> 1], wu = wr[i][j >> 1], ru = rv[i][j >> 1];
+                const float dyo = ((j & 1) ? bf_hi(du) : bf_lo(du)) * (DROP ? df[j] : 1.f);
+                const float xh = ((j & 1) ? bf_hi(xu) : bf_lo(xu)) * rs;
+                const float g = dyo * ((j & 1) ? bf_hi(wu) : bf_lo(wu)) * out_scale;
+                dwacc[i][j] += dyo * xh * okf;
+                v[j] = rs * (g - xh * dot);
+                if (dres) v[j] += (j & 1) ? bf_hi(ru) : bf_lo(ru);
+            }
+            u32x4 o, o2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = bf_pack(v[2 * j], v[2 * j + 1]);
+                o2[j] = bf_pack(bf_lo(o[j]) * df2[2 * j], bf_hi(o[j]) * df2[2 * j + 1]);
+            }
+            if (ok) {
+                *reinterpret_cast<u32x4*>(dx + base + c * 8) = o;
+                if (dx2) *reinterpret_cast<u32x4*>(dx2 + base + c * 8) = o2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!dw) return;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float s = dwacc[i][j];
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (sub == 0) red[wv][(ll + i * LPR) * 8 + j] = s;
+        }
+    __syncthreads();
+    for (int col = threadIdx.x; col < d; col += ROW_BLOCK) {
+        const float s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+        atomicAdd(dw + col, s);
+    }
+}
+
+// Grid for a grid-stride kernel over `groups` equal work units: as many workgroups as fit on the device at once, then
+// trimmed so that every workgroup takes the same number of units (no second, partly filled round).
+template <class Kernel>
+__host__ int balanced_grid(Kernel kernel, int& slots, int groups, int cap) {
+    if (slots == 0) {
+        int occ = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, ROW_BLOCK, 0) != hipSuccess || occ <= 0) occ = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = occ * cus;
+    }
+    const int s = slots < cap ? slots : cap;
+    const int iters = (groups + s - 1) / s;
+    const int g = (groups + iters - 1) / iters;
+    return g < 1 ? 1 : g;
+}
+
+template <int LPR, int PER, bool DROP>
+__host__ void launch_rmsnorm_bwd_rows_drop(const bf16* dy, const bf16* x, const bf16* w, const float* rstd, const bf16* dres, bf16* dx,
+                                           bf16* dx2, float* dw, int M, float out_scale, DropCfg drop, DropCfg drop2, hipStream_t stream) {
+    static int slots = 0;
+    const int groups = (M + 4 * (64 / LPR) - 1) / (4 * (64 / LPR));
+    const int grid = balanced_grid(rmsnorm_bwd_rows_kernel<LPR, PER, DROP>, slots, groups, 2048);   // the cap bounds the per-column atomics on dw
+    hipLaunchKernelGGL((rmsnorm_bwd_rows_kernel<LPR, PER, DROP>), dim3(grid), dim3(ROW_BLOCK), 0, stream, dy, x, w, rstd, dres, dx, dx2, dw,
+                       M, out_scale, drop, drop2);
+}
+template <int LPR, int PER>
+__host__ void launch_rmsnorm_bwd_rows(const bf16* dy, const bf16* x, const bf16* w, const float* rstd, const bf16* dres, bf16* dx,
+                                      bf16* dx2, float* dw, int M, float out_scale, DropCfg drop, DropCfg drop2, hipStream_t stream) {
+    if (drop.thresh) launch_rmsnorm_bwd_rows_drop<LPR, PER, true>(dy, x, w, rstd, dres, dx, dx2, dw, M, out_scale, drop, drop2, stream);
+    else launch_rmsnorm_bwd_rows_drop<LPR, PER, false>(dy, x, w, rstd, dres, dx, dx2, dw, M, out_scale, drop, drop2, stream);
+}
+
 // ---------------------------------------------------------------------------------------- embedding
 __global__ void __launch_bounds__(ROW_BLOCK) embedding_fwd_kernel(const long long* __restrict__ ids, const bf16* __restrict__ table,
                                                                  bf16* __restrict__ out, int M, int d, int vocab, DropCfg drop) {
@@ -421,11 +584,19 @@ extern "C" int paced_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
                                  float drop_p, uint32_t drop_seed, float drop2_p, uint32_t drop2_seed, void* stream) {
     PACED_CHECK_ARG(dy && x && w && rstd && dx, "paced_rmsnorm_bwd: null operand");
     PACED_CHECK_ARG(M > 0 && d > 0 && d % 8 == 0 && d <= 2048, "paced_rmsnorm_bwd: need M > 0 and d a multiple of 8 up to 2048 (got %d, %d)", M, d);
-    int grid = row_grid(M);
-    if (grid > 1024) grid = 1024;   // bounds the per-column atomics on dw
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid), dim3(ROW_BLOCK), 0, (hipStream_t)stream,
-                       (const bf16*)dy, (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx2, dw,
-                       M, d, out_scale, make_drop(drop_p, drop_seed), make_drop(drop2_p, drop2_seed));
+    const DropCfg drop = make_drop(drop_p, drop_seed), drop2 = make_drop(drop2_p, drop2_seed);
+#define BWD_ROWS(L, P) launch_rmsnorm_bwd_rows<L, P>((const bf16*)dy, (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx, \
+                                                    (bf16*)dx2, dw, M, out_scale, drop, drop2, (hipStream_t)stream)
+    if (d == 768) BWD_ROWS(16, 6);
+    else if (d == 512) BWD_ROWS(16, 4);
+    else {
+        int grid = row_grid(M);
+        if (grid > 1024) grid = 1024;   // bounds the per-column atomics on dw
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(grid), dim3(ROW_BLOCK), 0, (hipStream_t)stream,
+                           (const bf16*)dy, (const bf16*)x, (const bf16*)w, rstd, (const bf16*)dres, (bf16*)dx, (bf16*)dx2, dw,
+                           M, d, out_scale, drop, drop2);
+    }
+#undef BWD_ROWS
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }

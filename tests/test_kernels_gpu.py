@@ -277,6 +277,25 @@ def test_rmsnorm_bwd_second_output_is_masked_copy():
     assert torch.equal(dx2.float(), (dx.float() * mask).to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("M,d", [(70, 512), (131, 768), (37, 1024)])
+def test_rmsnorm_bwd_with_output_dropout_and_second_output(M, d):
+    """dy masked by the (seeded) dropout of the norm output, dx2 = dx masked by a second dropout; the row-group
+    kernel (d = 512, 768) and the one-row-per-wave kernel (other d) against autograd in fp32."""
+    x, w, dy = bf(rnd((M, d), 26, 2.0)), bf(1.0 + 0.1 * rnd((d,), 27)), bf(rnd((M, d), 28))
+    rstd = torch.empty(M, device=DEV)
+    K.rmsnorm_fwd(x, w, torch.empty_like(x), rstd)
+    dx, dx2 = torch.empty_like(x), torch.empty_like(x)
+    dw = torch.zeros(d, device=DEV)
+    K.rmsnorm_bwd(dy, x, w, rstd, dx, dx2=dx2, dw=dw, drop_p=0.1, drop_seed=5, drop2_p=0.1, drop2_seed=6)
+    m1 = K.dropout_mask(M * d, drop_p=0.1, drop_seed=5).view(M, d)
+    m2 = K.dropout_mask(M * d, drop_p=0.1, drop_seed=6).view(M, d)
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * wf).backward(dy.float() * m1)
+    assert ((dx.float() - xf.grad).abs() <= xf.grad.abs() * 2 ** -7 + 1e-3 * xf.grad.abs().max()).all()
+    assert torch.equal(dx2.float(), (dx.float() * m2).to(torch.bfloat16).float())
+    np.testing.assert_allclose(dw.cpu().numpy(), wf.grad.cpu().numpy(), rtol=2e-3, atol=2e-3 * wf.grad.abs().max().item())
+
+
 def test_embedding_fwd_bwd():
     V, d, M = 1000, 128, 777
     table = bf(rnd((V, d), 30))
