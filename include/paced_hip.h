@@ -70,6 +70,17 @@ int paced_gemm_bf16_batched(const void* A, const void* B, void* C,
  * phased tiles (one workgroup per CU, LDS ring).  Process-wide; meant for benchmarking and tests. */
 int paced_gemm_set_tile(int tile);
 
+/* Ring variant of the 64x64 / 128x128 kernels (a workgroup keeps several K steps in flight in its own LDS; taken when
+ * the output has at most a few tiles per CU, e.g. the decoder's two-token rows): 1 = on (default; the environment
+ * variable PACED_GEMM_RING=0 turns it off at load), 0 = off.  Same results bit for bit for the non-atomic epilogues.
+ * Process-wide; meant for benchmarking and tests. */
+int paced_gemm_set_ring(int on);
+
+/* Which kernel the calling process's most recent paced_gemm_bf16[_batched] launch used: the tile edge (64, 128 or 256;
+ * 256 is the phased kernel), plus 1 when the ring variant took it; 0 before the first launch.  For profilers that
+ * attribute launch times to kernels (bench.py's roofline leg). */
+int paced_gemm_last_kernel(void);
+
 /* ---- T5LayerNorm (RMS norm), HF:59-72; backward reached from lceT5.py:155 ------------------
  * fwd: y = bf16(x * rsqrt(mean(x^2)+eps) * w * out_scale) then dropout; rstd[M] saved (may be NULL).
  *      out_scale = d_model^-0.5 folds the tied-head rescale HF:1044-1045 into the final decoder norm.

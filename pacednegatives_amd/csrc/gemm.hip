@@ -178,7 +178,9 @@ struct TileOps {
     }
 
     // multiply the K step held in LDS buffer `buf` into the accumulators
-    template <bool NATURAL>
+    // RAW: transposed fragments are read by inline assembly (the builtin makes the compiler drain every LDS-DMA in
+    // flight first), followed by one wait for all LDS reads
+    template <bool NATURAL, bool RAW = false>
     static __device__ __forceinline__ void multiply(const char* smem, int buf, int wm, int wn, int lane, f32x4 (&acc)[MI][NJ]) {
         const char* lA = smem + buf * BUF_BYTES;
         const char* lB = lA + A_BYTES;
@@ -186,9 +188,13 @@ struct TileOps {
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[MI], fb[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fb[j] = read_frag<TB, BN>(lB, wn * TN + j * 16, kk, lane);
+            for (int j = 0; j < NJ; ++j) fb[j] = read_frag<TB, BN, RAW>(lB, wn * TN + j * 16, kk, lane);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = read_frag<TA, BM>(lA, wm * TM + i * 16, kk, lane);
+            for (int i = 0; i < MI; ++i) fa[i] = read_frag<TA, BM, RAW>(lA, wm * TM + i * 16, kk, lane);
+            if (RAW && (TA || TB)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -404,6 +410,79 @@ __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_bf16_kernel(Gem
     }
 }
 
+// Transposed fragment reads are inline assembly here (see read_frag): wait for all LDS reads of the
+// phase before its MFMAs, and keep the scheduler from hoisting anything above the wait.
+#define PACED_WAIT_LDS_READS()                                \
+    do {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                    \
+    } while (0)
+
+// a raw barrier that the instruction scheduler may not move anything across (MFMAs included)
+#define PACED_PINNED_BARRIER()                 \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+// Ring variant of the small-tile kernel for outputs with no more tiles than a few per CU (the decoder's two-token
+// rows): there occupancy cannot hide the staging latency, and one buffer with a full wait per K step makes every
+// K step cost a memory round trip (≈1 us; 48 of them in a row for K = 3072).  Here a workgroup owns ONE work item
+// and NS LDS buffers; NS - 1 K steps are in flight, the wait before step t leaves the NS - 2 younger ones pending.
+// Per K step: counted wait | raw barrier | issue step t + NS - 1 into the buffer step t - 1 was read from (every
+// wave has passed this barrier, so its fragment reads of step t - 1 have been consumed) | multiply step t.
+// No global load with a register destination precedes the loop (the epilogue comes after it and the kernel does
+// not loop over items), so the compiler adds no wait of its own ahead of the fragment reads.
+template <class Cfg, bool TA, bool TB, int EPI, int NS>
+__global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_ring_kernel(GemmParams p, int ntm, int ntn, int total_items) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NW = Cfg::WGM * Cfg::WGN;
+    constexpr int MI = BM / Cfg::WGM / 16, NJ = BN / Cfg::WGN / 16;
+    constexpr bool NATURAL = (EPI == EPI_ATOMIC_F32 || EPI == EPI_TOPK_DENSE || EPI == EPI_TOPK_FILTER);
+    using Ops = TileOps<Cfg, TA, TB>;
+    constexpr int PER = Ops::IA + Ops::IB;           // LDS-DMA instructions per wave and K step
+    static_assert(NS >= 3 && (NS - 2) * PER <= 63, "the pending count must fit the vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w / Cfg::WGN, wn = w % Cfg::WGN;
+
+    uint32_t offA[Ops::IA], offB[Ops::IB];
+#pragma unroll
+    for (int i = 0; i < Ops::IA; ++i) offA[i] = stage_offset<TA, BM>((i * NW + w) * 64 + lane, p.lda);
+#pragma unroll
+    for (int i = 0; i < Ops::IB; ++i) offB[i] = stage_offset<TB, BN>((i * NW + w) * 64 + lane, p.ldb);
+    const uint32_t kstrideA = TA ? (uint32_t)p.lda * 2u : 2u;
+    const uint32_t kstrideB = TB ? (uint32_t)p.ldb * 2u : 2u;
+
+    const WorkItem it = decode_item<Cfg, TA, TB>(p, xcd_remap(blockIdx.x, total_items), ntm, ntn);
+    const int nsteps = (it.kend - it.kbeg + BK - 1) / BK;
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nsteps)
+            Ops::stage(smem, s, (uint32_t)(it.kbeg + s * BK) * kstrideA, (uint32_t)(it.kbeg + s * BK) * kstrideB, w, it.rA, it.rB, offA, offB);
+    int buf = 0, nbuf = NS - 1;                      // buffer of step t, buffer of step t + NS - 1
+    for (int t = 0; t < nsteps; ++t) {
+        if (t + NS - 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PACED_PINNED_BARRIER();
+        if (t + NS - 1 < nsteps) {
+            const int k0 = it.kbeg + (t + NS - 1) * BK;
+            Ops::stage(smem, nbuf, (uint32_t)k0 * kstrideA, (uint32_t)k0 * kstrideB, w, it.rA, it.rB, offA, offB);
+        }
+        Ops::template multiply<NATURAL, true>(smem, buf, wm, wn, lane, acc);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
+    }
+    epilogue<Cfg, EPI>(p, batch_c<EPI>(p, it.b), it.m0, it.n0, wm, wn, lane, acc);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Phased 256x256 kernel.
 //
@@ -494,22 +573,6 @@ __device__ __forceinline__ void quadrant_mfma(const bf16x8 (&fa)[4][2], const bf
     __builtin_amdgcn_s_setprio(0);
     pin_quadrant(acc, ha, hb);
 }
-
-// Transposed fragment reads are inline assembly here (see read_frag): wait for all LDS reads of the
-// phase before its MFMAs, and keep the scheduler from hoisting anything above the wait.
-#define PACED_WAIT_LDS_READS()                                \
-    do {                                                      \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
-        __builtin_amdgcn_sched_barrier(0);                    \
-    } while (0)
-
-// a raw barrier that the instruction scheduler may not move anything across (MFMAs included)
-#define PACED_PINNED_BARRIER()                 \
-    do {                                       \
-        __builtin_amdgcn_sched_barrier(0);     \
-        __builtin_amdgcn_s_barrier();          \
-        __builtin_amdgcn_sched_barrier(0);     \
-    } while (0)
 
 __device__ __forceinline__ int ring_wrap(int x) { return x >= 10 ? x - 10 : x; }
 
@@ -829,15 +892,43 @@ int cu_count() {
     return cached[dev];
 }
 
+int g_last_kernel = 0;   // tile of the most recent launch (64, 128, 256), +1 when the ring variant took it
+int g_ring = -1;         // -1 = not set yet (PACED_GEMM_RING read on first use), 0 off, 1 on (paced_gemm_set_ring)
+bool ring_enabled() {
+    if (g_ring < 0) { const char* e = getenv("PACED_GEMM_RING"); g_ring = (e && atoi(e) == 0) ? 0 : 1; }
+    return g_ring != 0;
+}
+
+template <class Cfg, bool TA, bool TB, int EPI, int NS>
+int launch_ring(const GemmParams& p, int ntm, int ntn, int total, hipStream_t stream) {
+    constexpr int smem = NS * (Cfg::BM + Cfg::BN) * BK * 2;
+    if (smem > 65536) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<Cfg, TA, TB, EPI, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) { paced_set_error("hipFuncSetAttribute(%d bytes LDS) failed: %s", smem, hipGetErrorString(e)); return PACED_ERR_HIP; }
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_ring_kernel<Cfg, TA, TB, EPI, NS>), dim3(total), dim3(Cfg::WGM * Cfg::WGN * 64), smem, stream, p, ntm, ntn, total);
+    g_last_kernel = Cfg::BM + 1;
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
 template <class Cfg, bool TA, bool TB, int EPI>
 int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const int ntm = (p.M + Cfg::BM - 1) / Cfg::BM, ntn = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int ktiles = (p.K + BK - 1) / BK;
     constexpr bool PHASED = std::is_same<Cfg, CfgPhased>::value;
     const int slots = cu_count() * (PHASED ? 1 : std::is_same<Cfg, CfgTiny>::value ? 6 : 3);     // workgroups resident per CU
-    if (splits <= 0) {          // auto: fill the persistent grid once, keep >= 4 K steps per slice
+    constexpr bool RINGABLE = !PHASED && EPI != EPI_TOPK_DENSE && EPI != EPI_TOPK_FILTER;
+    const bool ring_on = ring_enabled();
+    if (splits <= 0) {          // auto: fill the grid once, keep >= 4 K steps per slice
         splits = 1;
-        if (EPI == EPI_ATOMIC_F32 && ntm * ntn * p.batch < slots) splits = slots / (ntm * ntn * p.batch);
+        // at most one workgroup per CU when the ring kernel will take the launch, else one per resident slot
+        const int fill = (RINGABLE && ring_on && ntm * ntn * p.batch <= cu_count()) ? cu_count() : slots;
+        if (EPI == EPI_ATOMIC_F32 && ntm * ntn * p.batch < fill) splits = fill / (ntm * ntn * p.batch);
         if (splits > ktiles / 4) splits = ktiles / 4 > 0 ? ktiles / 4 : 1;
     }
     if (splits > ktiles) splits = ktiles;
@@ -846,6 +937,19 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     splits = (ktiles + tiles_per_split - 1) / tiles_per_split;
     const int total = ntm * ntn * splits * p.batch;
     const int grid = total < slots ? total : slots;
+    if constexpr (RINGABLE) {
+        // few tiles per CU: latency is hidden inside the workgroup (ring of K steps) instead of by occupancy
+        const int per_cu = (total + cu_count() - 1) / cu_count();
+        if (ring_on && tiles_per_split >= 3) {
+            if constexpr (std::is_same<Cfg, CfgTiny>::value) {
+                if (per_cu == 1) return launch_ring<Cfg, TA, TB, EPI, 8>(p, ntm, ntn, total, stream);
+                if (per_cu == 2) return launch_ring<Cfg, TA, TB, EPI, 4>(p, ntm, ntn, total, stream);
+                if (per_cu == 3) return launch_ring<Cfg, TA, TB, EPI, 3>(p, ntm, ntn, total, stream);
+            } else {
+                if (per_cu == 1) return launch_ring<Cfg, TA, TB, EPI, 4>(p, ntm, ntn, total, stream);
+            }
+        }
+    }
     constexpr int smem = PHASED ? 163840 : (Cfg::BM + Cfg::BN) * BK * 2;
     if (smem > 65536) {
         static bool attr_set = false;     // one flag per template instantiation
@@ -859,12 +963,21 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     }
     if constexpr (PHASED) hipLaunchKernelGGL((gemm_phased_kernel<TA, TB, EPI>), dim3(grid), dim3(512), smem, stream, p, ntm, ntn, total);
     else hipLaunchKernelGGL((gemm_bf16_kernel<Cfg, TA, TB, EPI>), dim3(grid), dim3(Cfg::WGM * Cfg::WGN * 64), smem, stream, p, ntm, ntn, total);
+    g_last_kernel = Cfg::BM;
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }
 
 template <bool TA, bool TB, int EPI>
 int launch(const GemmParams& p, int splits, hipStream_t stream) {
+    if (EPI == EPI_ATOMIC_F32 && splits <= 0 && g_force_tile == 0 && ring_enabled()) {
+        // Short contraction into a mid-sized output (the decoder's weight gradients): the launch is bound by the
+        // output, every split adds the whole output once more in atomics, and a big tile leaves CUs empty; take
+        // 64x64 tiles, no more splits than it takes to give every CU a workgroup, and the ring kernel.
+        const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.batch;
+        const int ktiles = (p.K + BK - 1) / BK;
+        if (ktiles >= 3 && ktiles <= 32 && t64 <= 3LL * cu_count()) return launch_cfg<CfgTiny, TA, TB, EPI>(p, 0, stream);
+    }
     bool large;
     if (g_force_tile == 128) large = false;
     else if (g_force_tile == 256) large = true;
@@ -880,7 +993,9 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
     if (large && rows16) return launch_cfg<CfgPhased, TA, TB, EPI>(p, splits, stream);
     // fewer 128x128 tiles than CUs and no K split to make up for it: quarter-size tiles
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
-    const bool tiny = g_force_tile == 64 || (g_force_tile == 0 && t128 < cu_count() && (EPI != EPI_ATOMIC_F32 || splits == 1));
+    // (with the ring kernel half a grid of 128x128 tiles beats more than two 64x64 tiles per CU: half the operand traffic)
+    const int tiny_below = ring_enabled() ? cu_count() / 2 : cu_count();
+    const bool tiny = g_force_tile == 64 || (g_force_tile == 0 && t128 < tiny_below && (EPI != EPI_ATOMIC_F32 || splits == 1));
     if (tiny) return launch_cfg<CfgTiny, TA, TB, EPI>(p, splits, stream);
     return launch_cfg<CfgSmall, TA, TB, EPI>(p, splits, stream);
 }
@@ -906,6 +1021,13 @@ int dispatch_epi(const GemmParams& p, int epi, int splits, hipStream_t s) {
 extern "C" int paced_gemm_set_tile(int tile) {
     PACED_CHECK_ARG(tile == 0 || tile == 64 || tile == 128 || tile == 256, "paced_gemm_set_tile: tile must be 0 (auto), 64, 128 or 256");
     g_force_tile = tile;
+    return PACED_OK;
+}
+
+extern "C" int paced_gemm_last_kernel(void) { return g_last_kernel; }
+
+extern "C" int paced_gemm_set_ring(int on) {
+    g_ring = on ? 1 : 0;
     return PACED_OK;
 }
 

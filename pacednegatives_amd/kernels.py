@@ -14,7 +14,8 @@ EPI_BF16, EPI_RES_DROP, EPI_RELU_DROP, EPI_MASK, EPI_F32, EPI_ATOMIC_F32, EPI_MA
 BF16, F32, I64, I32, U8 = torch.bfloat16, torch.float32, torch.int64, torch.int32, torch.uint8
 
 # When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
-# ((trans_a, trans_b, epilogue), algorithmic FLOPs, start, end) is appended (bench.py's roofline leg).
+# ((trans_a, trans_b, epilogue, kernel), algorithmic FLOPs, start, end) is appended (bench.py's roofline leg);
+# kernel is paced_gemm_last_kernel(): 256 = phased kernel, 128 / 64 = small tiles, +1 = their ring variant.
 PROFILE = None
 
 
@@ -76,7 +77,7 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
                                    _stream()), "paced_gemm_bf16")
     if prof is not None:
         e1.record()
-        prof.append(((int(trans_a), int(trans_b), int(epilogue)), 2.0 * M * N * K, e0, e1))
+        prof.append(((int(trans_a), int(trans_b), int(epilogue), lib.paced_gemm_last_kernel()), 2.0 * M * N * K, e0, e1))
     return c
 
 
@@ -95,8 +96,13 @@ def gemm_batched(a, b, c, *, M, N, K, lda, ldb, ldc, batch, stride_a, stride_b, 
                                            alpha, splits, batch, stride_a, stride_b, stride_c, _stream()), "paced_gemm_bf16_batched")
     if prof is not None:
         e1.record()
-        prof.append(((int(trans_a), int(trans_b), int(epilogue)), 2.0 * M * N * K * batch, e0, e1))
+        prof.append(((int(trans_a), int(trans_b), int(epilogue), lib.paced_gemm_last_kernel()), 2.0 * M * N * K * batch, e0, e1))
     return c
+
+
+def gemm_set_ring(on: bool):
+    """Ring variant of the small-tile kernels on (default) or off (benchmarks and tests)."""
+    _lib.check(_lib.load().paced_gemm_set_ring(int(bool(on))), "paced_gemm_set_ring")
 
 
 def gemm_set_tile(tile: int):

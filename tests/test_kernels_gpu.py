@@ -239,6 +239,51 @@ def test_gemm_rejects_bad_shapes():
         K.gemm(A, B, torch.zeros(64, 64, device=DEV), epilogue=K.EPI_F32)
 
 
+@pytest.mark.parametrize("M,N,K_", [(1088, 768, 768), (1088, 768, 3072), (1088, 2304, 768), (1088, 3072, 768), (200, 264, 1088)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize("epi", ["bf16", "res_drop", "relu_drop", "mask", "f32"])
+def test_gemm_ring_kernel_matches_the_single_buffer_kernel(M, N, K_, ta, tb, epi):
+    """Shapes with a few tiles per CU (the decoder's) take the ring kernel; it multiplies the same K steps in the same
+    order, so every non-atomic epilogue must give the same bits as the kernel it replaces."""
+    if ta and (M % 8 or epi != "bf16" and (M, N, K_) != (1088, 768, 768)):
+        pytest.skip("transposed A: one epilogue per shape is enough")
+    a = bf(rnd((K_, M) if ta else (M, K_), 70, 0.3))
+    b = bf(rnd((K_, N) if tb else (N, K_), 71, 0.3))
+    aux = bf(rnd((M, N), 72))
+    kw = {"bf16": dict(epilogue=K.EPI_BF16), "res_drop": dict(epilogue=K.EPI_RES_DROP, aux=aux, drop_p=0.1, drop_seed=9),
+          "relu_drop": dict(epilogue=K.EPI_RELU_DROP, drop_p=0.1, drop_seed=9), "mask": dict(epilogue=K.EPI_MASK, aux=aux),
+          "f32": dict(epilogue=K.EPI_F32)}[epi]
+    outs = []
+    try:
+        for ring in (True, False):
+            K.gemm_set_ring(ring)
+            c = torch.zeros(M, N, device=DEV, dtype=torch.float32 if epi == "f32" else torch.bfloat16)
+            K.gemm(a, b, c, trans_a=ta, trans_b=tb, **kw)
+            outs.append(c)
+    finally:
+        K.gemm_set_ring(True)
+    assert torch.equal(outs[0], outs[1])
+    if epi in ("bf16", "f32"):
+        want = (a.float().t() if ta else a.float()) @ (b.float() if tb else b.float().t())
+        assert (outs[0].float() - want).abs().max() <= 2e-2 * want.abs().max()
+
+
+@pytest.mark.parametrize("M,N,K_", [(768, 768, 1088), (3072, 768, 1088), (64, 768, 1088), (768, 776, 1000)])
+def test_gemm_ring_kernel_atomic_accumulate(M, N, K_):
+    """Weight-gradient form (both operands K-strided, fp32 atomics into an existing buffer) with and without the ring."""
+    a, b = bf(rnd((K_, M), 73, 0.3)), bf(rnd((K_, N), 74, 0.3))
+    base = rnd((M, N), 75).to(DEV)
+    want = base + a.float().t() @ b.float()
+    try:
+        for ring in (True, False):
+            K.gemm_set_ring(ring)
+            c = base.clone()
+            K.gemm(a, b, c, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)
+            assert (c - want).abs().max() <= 1e-3 * want.abs().max()
+    finally:
+        K.gemm_set_ring(True)
+
+
 # --------------------------------------------------------------------------------- norm / embedding
 @pytest.mark.parametrize("M,d", [(5, 128), (333, 768), (64, 1024)])
 def test_rmsnorm_fwd_bwd(M, d):

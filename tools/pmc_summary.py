@@ -30,13 +30,17 @@ for n in sorted(set(fetch) | set(write)):
     rd = 2.0 * fetch[n][1] * 1024 / launches
     wr = write[n][1] * 1024 / launches
     out[n] = {"launches": launches, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-gemm = [v for k, v in out.items() if "gemm_bf16_kernel" in k or "gemm_phased_kernel" in k]     # every paced_gemm_bf16 launch
-tot_l = sum(v["launches"] for v in gemm)
+def pooled(names):
+    sel = [v for k, v in out.items() if any(n in k for n in names)]
+    n = sum(v["launches"] for v in sel)
+    return {"launches": n, "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / max(1, n)}
+
 summary = {"per_kernel": out,
-           "gemm_bf16_kernel": {"launches": tot_l,
-                                "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gemm) / max(1, tot_l)},
+           "gemm_phased_kernel": pooled(["gemm_phased_kernel"]),                                              # the dominant kernel
+           "all_gemm_kernels": pooled(["gemm_phased_kernel", "gemm_bf16_kernel", "gemm_ring_kernel"]),        # every paced_gemm_bf16 launch
            "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as read; KiB -> bytes; per launch = total / dispatches"}
 json.dump(summary, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
     print(f"{k[:64]:64s} n={v['launches']:5d} rd/launch={v['read_bytes_per_launch']/1e6:9.1f} MB wr/launch={v['write_bytes_per_launch']/1e6:9.1f} MB")
-print("gemm avg bytes/launch", summary["gemm_bf16_kernel"])
+print("phased gemm avg bytes/launch", summary["gemm_phased_kernel"])
+print("all gemm avg bytes/launch", summary["all_gemm_kernels"])
