@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int DK = 64;
+constexpr float LOG2E = 1.4426950408889634f;
 
 // ---- LDS tile images: [rows][64] bf16, 128-byte rows --------------------------------------------
 // row image: 16-byte chunk c of row r stored at chunk c ^ ((r>>1)&7): conflict-free ds_read_b128
@@ -182,21 +183,22 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
+        const float m_log2 = m_new * LOG2E;          // exp(s - m) as exp2(s * log2(e) - m * log2(e)): one fma, one v_exp_f32
         const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3);   // key rows padded to quads
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
-                float f[4] = {1.f, 1.f, 1.f, 1.f};
+                bool keep[4] = {true, true, true, true};      // the 1/(1-p) scale of kept probabilities goes into the final normalisation
                 if (DROP) {
                     const int key = kt * 64 + 32 * j + acc_row(r, hh);      // multiple of 4; registers r+1..r+3 hold key+1..key+3
-                    drop_factor4_on(a.drop, dbase + key, f);
+                    drop_keep4_on(a.drop, dbase + key, keep);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = __expf(s[j][r + e] - m_new);
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(s[j][r + e], LOG2E, -m_log2));
                     psum += pe;
-                    s[j][r + e] = pe * f[e];
+                    s[j][r + e] = keep[e] ? pe : 0.f;
                 }
             }
         l_run = l_run * alpha + psum;
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
             }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
+    const float inv = (DROP ? a.drop.scale : 1.f) / l_tot;
     if (q < S) {
         if (hh == 0 && a.lse) a.lse[((size_t)n * a.H + h) * S + q] = m_run + __logf(l_tot);
         bf16* orow = a.out + (rowbase + q) * a.ldo + h * DK;

@@ -104,6 +104,15 @@ __device__ __forceinline__ void drop_factor4_on(const DropCfg& d, uint64_t idx4,
     f[2] = (h1 & 0xffffu) >= d.thresh ? d.scale : 0.f;
     f[3] = (h1 >> 16) >= d.thresh ? d.scale : 0.f;
 }
+// keep decisions only (dropout known to be on): for callers that apply the 1/(1-p) scale elsewhere
+__device__ __forceinline__ void drop_keep4_on(const DropCfg& d, uint64_t idx4, bool (&k)[4]) {
+    uint32_t h0, h1;
+    paced_drop_words(d.seed, idx4 >> 2, h0, h1);
+    k[0] = (h0 & 0xffffu) >= d.thresh;
+    k[1] = (h0 >> 16) >= d.thresh;
+    k[2] = (h1 & 0xffffu) >= d.thresh;
+    k[3] = (h1 >> 16) >= d.thresh;
+}
 // factors of 8 consecutive elements starting at a multiple of 4
 __device__ __forceinline__ void drop_factor8(const DropCfg& d, uint64_t idx4, float (&f)[8]) {
     float a[4], b[4];
