@@ -113,7 +113,7 @@ def run_train(args, rank, world, device):
                 "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s", "frac": tot_f / tot_t / BF16_DENSE_PEAK, "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; profiles/r1_pmc_traffic.json)",
                 "flops_per_launch": tot_f / tot_n, "launches": tot_n, "avg_launch_us": tot_t / tot_n * 1e6,
-                "slowest_variant": {"trans_a,trans_b,epilogue": list(dom[0][:3]), "TFLOP/s": dom[1][0] / dom[1][1] / 1e12,
+                "largest_share_variant": {"trans_a,trans_b,epilogue": list(dom[0][:3]), "TFLOP/s": dom[1][0] / dom[1][1] / 1e12,
                                     "launches": dom[1][2], "avg_launch_us": dom[1][1] / dom[1][2] * 1e6},
                 "share_of_step": tot_t / (elapsed / args.steps),
                 "all_gemm_launches": {"kernels": "gemm_phased_kernel + gemm_bf16_kernel + gemm_ring_kernel", "launches": all_n,
