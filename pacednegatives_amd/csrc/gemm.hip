@@ -926,8 +926,11 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const bool ring_on = ring_enabled();
     if (splits <= 0) {          // auto: fill the grid once, keep >= 4 K steps per slice
         splits = 1;
-        // at most one workgroup per CU when the ring kernel will take the launch, else one per resident slot
-        const int fill = (RINGABLE && ring_on && ntm * ntn * p.batch <= cu_count()) ? cu_count() : slots;
+        // one workgroup per CU, or no split at all up to the ring kernel's three per CU, when it will take the launch;
+        // else one per resident slot
+        const int tiles = ntm * ntn * p.batch;
+        const bool tiny_cfg = std::is_same<Cfg, CfgTiny>::value;
+        const int fill = !(RINGABLE && ring_on) ? slots : tiles <= cu_count() ? cu_count() : (tiny_cfg && tiles <= 3 * cu_count()) ? tiles : slots;
         if (EPI == EPI_ATOMIC_F32 && ntm * ntn * p.batch < fill) splits = fill / (ntm * ntn * p.batch);
         if (splits > ktiles / 4) splits = ktiles / 4 > 0 ? ktiles / 4 : 1;
     }
