@@ -123,10 +123,11 @@ def run_train(args, rank, world, device):
     tuples_per_s = world * B * args.steps / elapsed
     flops_per_tuple = 4 * (1 + nneg) * F
     out = {
-        "metric": "training tuples/sec (q + 1+K docs) at T5-base, K=16", "value": tuples_per_s, "unit": "tuples/s",
+        "metric": "training triples/sec (q + 1+K docs) at T5-base, K=16", "value": tuples_per_s, "unit": "triples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"lceT5 training_step, {args.model} random-init, K={nneg} negatives, seq_len={S}, "
+        "config": {"workload": f"lceT5 training_step, {args.model} random-init, one triple = query + positive + K={nneg} negatives "
+                               f"(1+K documents), seq_len={S}, "
                                f"{B} tuples per GPU (global batch {B * world}), dropout {args.dropout}, "
                                "reference-faithful 4 forwards + backward + 2 AdamW",
                    "parallelism": f"dp{world}", "global_batch": B * world, "seq_len": S},
@@ -161,7 +162,7 @@ def cpu_baseline(args, dims):
             t_used += dt; steps += 1
         if t_used > 25.0:
             break
-    return {"value": B * steps / t_used, "unit": "tuples/s", "cores": threads, "kind": "port",
+    return {"value": B * steps / t_used, "unit": "triples/s", "cores": threads, "kind": "port",
             "sample": f"{steps} timed steps (after 1 warm-up) of B=1 tuple (1+{args.n_neg} sequences x {args.seq} tokens), "
                       f"{args.model} dims, fp32, dropout 0, torch CPU"}
 
