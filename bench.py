@@ -169,7 +169,7 @@ def cpu_baseline(args, dims):
 
 def run_mining(args, rank, world, device):
     """Secondary figure: pool rows are sharded over ranks, queries replicated, shard results merged."""
-    from pacednegatives_amd import kernels as K
+    from pacednegatives_amd import kernels as K, mining
     import torch.distributed as dist
     Q, D, k = args.mine_queries, 768, args.mine_k
     Np = args.mine_pool // world
@@ -184,14 +184,7 @@ def run_mining(args, rank, world, device):
     ws = torch.empty(K._lib.load().paced_pool_topk_workspace_bytes(Q, k), dtype=torch.uint8, device=device)
 
     def once():
-        s, i = K.pool_topk(queries, pool, k, index_base=rank * Np, workspace=ws)
-        if world > 1:
-            gs = [torch.empty_like(s) for _ in range(world)]
-            gi = [torch.empty_like(i) for _ in range(world)]
-            dist.all_gather(gs, s)
-            dist.all_gather(gi, i)
-            s, i = K.topk_merge(torch.cat(gs, 1).contiguous(), torch.cat(gi, 1).contiguous(), k)
-        return s, i
+        return mining.pool_topk_sharded(queries, pool, k, rank * Np, workspace=ws)
     once()
     if world > 1:
         dist.barrier()
@@ -217,6 +210,45 @@ def run_mining(args, rank, world, device):
                          "algorithmic_bytes": bytes_alg, "traffic": None}}
 
 
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a torchrun environment: start N fresh processes of this script, one per
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relay rank 0's JSON line and return non-zero if any rank
+    failed.  The parent makes no GPU call, before or after."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):      # a dead rank leaves the others waiting in a collective
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad or failed:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,9 +268,11 @@ def main():
     ap.add_argument("--mine_iters", type=int, default=2)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))         # this process never touches the GPU
     from pacednegatives_amd.trainer import init_distributed
     rank, world, local = init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")

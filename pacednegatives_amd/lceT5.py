@@ -237,6 +237,7 @@ class LCEModel:
         self.logged = OrderedDict()
         self._opts = None
         self._base_seed = int(self.hparams.get("dropout_seed", 1234) or 1234)
+        self.on_gradients_ready = None
 
     # ---- Lightning-like plumbing
     def log(self, name, value):
@@ -282,7 +283,8 @@ class LCEModel:
     def _forward_pair(self, p, n, save, call, after_encoder=None):
         """Run the positive and negative batches; one packed call when their lengths agree."""
         eng = self.model.engine
-        seed = (self._base_seed * 0x9E3779B1 + self.global_step * 8 + call) & 0xFFFFFFFF
+        # every rank draws its own masks, as the independent RNG streams of DDP ranks do in the reference
+        seed = (self._base_seed * 0x9E3779B1 + parallel.rank() * 0x632BE5AB + self.global_step * 8 + call) & 0xFFFFFFFF
         B = p["input_ids"].shape[0]
         if p["input_ids"].shape[1] == n["input_ids"].shape[1]:
             ids = torch.cat([p["input_ids"].to(self.device), n["input_ids"].to(self.device)], 0)
@@ -387,6 +389,8 @@ class LCEModel:
             weights, stats = meta_update(loss)
         # main update                                                                        :156-157
         parallel.allreduce_sum_(self.model.params.g32)          # one all-reduce over the flat fp32 gradient buffer
+        if self.on_gradients_ready is not None:                 # tests: the summed gradients, before the update clears them
+            self.on_gradients_ready(self)
         opt.step(grad_scale=1.0 / world)
         scheduler.step()
         opt.zero_grad()

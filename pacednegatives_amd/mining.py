@@ -17,28 +17,27 @@ from typing import Iterable, List, Optional, Sequence
 import torch
 
 from . import kernels as K
+from . import parallel
 
 
-def pool_topk(query_emb: torch.Tensor, pool_emb: torch.Tensor, k: int, index_base: int = 0):
+def pool_topk(query_emb: torch.Tensor, pool_emb: torch.Tensor, k: int, index_base: int = 0, workspace=None):
     """(scores f32 [Q,k], rows i64 [Q,k]) best first; entries beyond the pool size are (-inf, -1)."""
     q = query_emb.to(torch.bfloat16).contiguous()
     p = pool_emb.to(torch.bfloat16).contiguous()
-    return K.pool_topk(q, p, k, index_base=index_base)
+    return K.pool_topk(q, p, k, index_base=index_base, workspace=workspace)
 
 
-def pool_topk_sharded(query_emb: torch.Tensor, pool_shard: torch.Tensor, k: int, shard_row_offset: int):
+def pool_topk_sharded(query_emb: torch.Tensor, pool_shard: torch.Tensor, k: int, shard_row_offset: int, workspace=None):
     """Every rank holds a contiguous slice of pool rows starting at ``shard_row_offset`` and the full
     query set; returns the global top-k on every rank (all_gather of per-shard results + merge)."""
-    import torch.distributed as dist
-    s, i = pool_topk(query_emb, pool_shard, k, index_base=shard_row_offset)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    s, i = pool_topk(query_emb, pool_shard, k, index_base=shard_row_offset, workspace=workspace)
+    world = parallel.world_size()
+    if world == 1:
         return s, i
-    world = dist.get_world_size()
-    gs = [torch.empty_like(s) for _ in range(world)]
-    gi = [torch.empty_like(i) for _ in range(world)]
-    dist.all_gather(gs, s)
-    dist.all_gather(gi, i)
-    return K.topk_merge(torch.cat(gs, 1).contiguous(), torch.cat(gi, 1).contiguous(), k)
+    Q = s.shape[0]
+    gs = parallel.all_gather_stack(s).permute(1, 0, 2).reshape(Q, world * k).contiguous()      # [Q, W*k]
+    gi = parallel.all_gather_stack(i).permute(1, 0, 2).reshape(Q, world * k).contiguous()
+    return K.topk_merge(gs, gi, k)
 
 
 def easy_to_hard(rows_best_first: torch.Tensor) -> torch.Tensor:

@@ -34,6 +34,27 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def all_gather_stack(t: torch.Tensor) -> torch.Tensor:
+    """[W, *t.shape]: every rank's ``t`` (same shape and dtype on all ranks), on ``t``'s device.
+
+    RCCL gathers straight into one preallocated device buffer.  The gloo backend (CPU tests, and rehearsals in which
+    several ranks share one GPU) is given host tensors: the device tensor is copied to the host first, which also
+    orders the exchange after the kernels that produce ``t`` on the calling stream."""
+    d = _dist()
+    if not d or d.get_world_size() == 1:
+        return t.unsqueeze(0)
+    W = d.get_world_size()
+    t = t.contiguous()
+    if d.get_backend() == "nccl":
+        out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        d.all_gather_into_tensor(out, t)
+        return out
+    host = t.detach().cpu()
+    parts = [torch.empty_like(host) for _ in range(W)]
+    d.all_gather(parts, host)
+    return torch.stack(parts, 0).to(t.device)
+
+
 def grad_scale() -> float:
     """Factor that turns a summed gradient into the mean over ranks."""
     return 1.0 / world_size()
