@@ -240,8 +240,9 @@ def launch_ranks(n: int) -> int:
         time.sleep(0.2)
     codes = [p.wait() for p in procs]
     reader.join(timeout=10)
-    sys.stdout.write(b"".join(chunks).decode())
-    sys.stdout.flush()
+    for line in b"".join(chunks).decode(errors="replace").splitlines():
+        # stdout carries rank 0's JSON line only; whatever else a rank printed there (gloo's connection notice) goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad or failed:
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)

@@ -27,7 +27,7 @@ def main(out_dir):
     rank, world, local = init_distributed()
     torch.cuda.set_device(local)
     dims = NAMED["t5-tiny"]
-    hp = {"model_name": "t5-tiny", "total_steps": 10, "eta": 9.5, "batch_size": B // world, "lr": 1e-3, "meta_lr": 1e-2,
+    hp = {"model_name": "t5-tiny", "total_steps": 10, "eta": 35.0, "batch_size": B // world, "lr": 1e-3, "meta_lr": 1e-2,
           "n": NNEG, "warmup_steps": 0, "use_mean": False, "ignore_index": -100, "dropout": 0.0, "seed": 0}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -69,7 +69,7 @@ def test_two_rank_step_equals_one_rank_on_the_whole_batch(runs):
         assert np.linalg.norm(g1) > 0
         l2 = np.linalg.norm(ga - g1) / np.linalg.norm(g1)
         print(f"step {it}: |g(W=2) - g(W=1)| / |g(W=1)| = {l2:.3e}")
-        assert l2 < 1e-3
+        assert l2 < 1e-6            # measured 4e-8: fp32 atomics in another order
     assert np.array_equal(two[0]["p32"], two[1]["p32"]), "ranks hold different parameters after two updates"
     # AdamW's first steps move every weight by ~lr whatever the gradient's size, so entries whose tiny gradient
     # flips sign between the two summation orders differ by up to 2 lr per step; they must be rare
