@@ -200,6 +200,22 @@ int paced_pool_topk(const void* queries, const void* pool, int Q, long long Np, 
 int paced_topk_merge(const float* scores, const long long* idx, int Q, int total, int k,
                      float* out_scores, long long* out_idx, void* stream);
 
+/* ---- paced_pool_topk for callers that cannot allocate -------------------------------------------
+ * No counterpart in the reference.  For callers that may not call hipMalloc or take a workspace from an
+ * allocator: code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same
+ * arguments, results and order as paced_pool_topk, without the workspace: the candidate lists live in an
+ * array inside the library's device image (paced_pool_topk_static_bytes() bytes, about 17 MiB, held by every
+ * GPU the library runs on until the process ends; its per-device address is looked up on the first call on
+ * that device).  Limits: Q <= paced_pool_topk_static_max_queries() (64), k <= paced_pool_topk_static_max_k()
+ * (1024); larger requests fail with an error naming the limit.  The call allocates and frees nothing.  All
+ * calls on one GPU share that GPU's array: calls that overlap there (two streams, two threads) race; calls
+ * on one stream, or otherwise ordered, are safe, and a call needs nothing cleared by its predecessor. */
+size_t paced_pool_topk_static_bytes(void);
+int paced_pool_topk_static_max_queries(void);
+int paced_pool_topk_static_max_k(void);
+int paced_pool_topk_static(const void* queries, const void* pool, int Q, long long Np, int D, int k,
+                           long long index_base, float* out_scores, long long* out_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,10 @@ SIGNATURES = {
     "paced_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp]),
     "paced_pool_topk_workspace_bytes": (_sz, [_i, _i]),
     "paced_pool_topk": (_i, [_vp, _vp, _i, _ll, _i, _i, _ll, _vp, _vp, _vp, _sz, _vp]),
+    "paced_pool_topk_static_bytes": (_sz, []),
+    "paced_pool_topk_static_max_queries": (_i, []),
+    "paced_pool_topk_static_max_k": (_i, []),
+    "paced_pool_topk_static": (_i, [_vp, _vp, _i, _ll, _i, _i, _ll, _vp, _vp, _vp]),
     "paced_topk_merge": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
 }
 

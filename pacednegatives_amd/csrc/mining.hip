@@ -11,6 +11,7 @@
 // stays about k.  Candidate capacity 2k + CH_MAX per query makes overflow impossible.  A final
 // bitonic sort in LDS orders each query's k keys: (score descending, pool row ascending).
 #include "gemm.h"
+#include <mutex>
 
 namespace {
 
@@ -180,23 +181,13 @@ extern "C" size_t paced_pool_topk_workspace_bytes(int Q, int k) {
     return head + (size_t)Q * cap_for(k) * 8;
 }
 
-extern "C" int paced_pool_topk(const void* queries, const void* pool, int Q, long long Np, int D, int k,
-                               long long index_base, float* out_scores, long long* out_idx,
-                               void* workspace, size_t workspace_bytes, void* stream) {
-    PACED_CHECK_ARG(queries && pool && out_scores && out_idx && workspace, "paced_pool_topk: null operand");
-    PACED_CHECK_ARG(Q > 0 && Np > 0 && D > 0 && D % 64 == 0, "paced_pool_topk: need Q, Np > 0 and D a multiple of 64 (got %d, %lld, %d)", Q, Np, D);
-    PACED_CHECK_ARG(k > 0 && k <= K_MAX, "paced_pool_topk: k must be in [1, %d] (got %d)", K_MAX, k);
-    PACED_CHECK_ARG(Np < 0xFFFFFFFFll, "paced_pool_topk: at most 2^32-1 pool rows per call (shard larger pools)");
-    PACED_CHECK_ARG(workspace_bytes >= paced_pool_topk_workspace_bytes(Q, k), "paced_pool_topk: workspace too small (%zu < %zu)",
-                    workspace_bytes, paced_pool_topk_workspace_bytes(Q, k));
-    PACED_CHECK_ARG(((uintptr_t)queries & 15) == 0 && ((uintptr_t)pool & 15) == 0 && ((uintptr_t)workspace & 255) == 0, "paced_pool_topk: misaligned buffers");
-    hipStream_t s = (hipStream_t)stream;
-    const int cap = cap_for(k);
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(workspace);
-    float* thr = reinterpret_cast<float*>(cnt + Q);
-    const size_t head = ((size_t)Q * 8 + 255) / 256 * 256;
-    unsigned long long* cand = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + head);
+namespace {
 
+// The sweep itself: candidate lists, counters and thresholds live in memory the caller of this function owns;
+// `cap` slots per query, chunks of at most `ch_max` rows (cap >= 2k + ch_max and cap >= CH_FIRST).
+int pool_topk_sweep(const void* queries, const void* pool, int Q, long long Np, int D, int k, long long index_base,
+                    float* out_scores, long long* out_idx, unsigned int* cnt, float* thr, unsigned long long* cand,
+                    int cap, int ch_max, hipStream_t s) {
     GemmParams p = {};
     p.B = (const bf16*)queries; p.N = Q; p.K = D; p.lda = D; p.ldb = D; p.ldc = 0;
     p.k_per_split = D; p.alpha = 1.f; p.mask_scale = 1.f; p.drop = make_drop(0.f, 0);
@@ -214,7 +205,7 @@ extern "C" int paced_pool_topk(const void* queries, const void* pool, int Q, lon
     PACED_CHECK_LAUNCH();
     done = chunk;
     while (done < Np) {
-        long long next = done < CH_MAX ? done : CH_MAX;       // double until CH_MAX
+        long long next = done < ch_max ? done : ch_max;       // double until ch_max
         if (next > Np - done) next = Np - done;
         p.A = (const bf16*)pool + (size_t)done * D; p.M = (int)next; p.tk_row_base = (unsigned int)done;
         if (int e = paced_gemm_launch(p, false, false, EPI_TOPK_FILTER, 1, s)) return e;
@@ -228,6 +219,88 @@ extern "C" int paced_pool_topk(const void* queries, const void* pool, int Q, lon
     hipLaunchKernelGGL(topk_emit_kernel, dim3(Q), dim3(256), (size_t)npad * 8, s, cand, cnt, cap, k, npad, index_base, out_scores, out_idx);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
+}
+
+}  // namespace
+
+extern "C" int paced_pool_topk(const void* queries, const void* pool, int Q, long long Np, int D, int k,
+                               long long index_base, float* out_scores, long long* out_idx,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    PACED_CHECK_ARG(queries && pool && out_scores && out_idx && workspace, "paced_pool_topk: null operand");
+    PACED_CHECK_ARG(Q > 0 && Np > 0 && D > 0 && D % 64 == 0, "paced_pool_topk: need Q, Np > 0 and D a multiple of 64 (got %d, %lld, %d)", Q, Np, D);
+    PACED_CHECK_ARG(k > 0 && k <= K_MAX, "paced_pool_topk: k must be in [1, %d] (got %d)", K_MAX, k);
+    PACED_CHECK_ARG(Np < 0xFFFFFFFFll, "paced_pool_topk: at most 2^32-1 pool rows per call (shard larger pools)");
+    PACED_CHECK_ARG(workspace_bytes >= paced_pool_topk_workspace_bytes(Q, k), "paced_pool_topk: workspace too small (%zu < %zu)",
+                    workspace_bytes, paced_pool_topk_workspace_bytes(Q, k));
+    PACED_CHECK_ARG(((uintptr_t)queries & 15) == 0 && ((uintptr_t)pool & 15) == 0 && ((uintptr_t)workspace & 255) == 0, "paced_pool_topk: misaligned buffers");
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(workspace);
+    float* thr = reinterpret_cast<float*>(cnt + Q);
+    const size_t head = ((size_t)Q * 8 + 255) / 256 * 256;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + head);
+    return pool_topk_sweep(queries, pool, Q, Np, D, k, index_base, out_scores, out_idx, cnt, thr, cand, cap_for(k), CH_MAX,
+                           (hipStream_t)stream);
+}
+
+// ---- the same selection for callers that cannot allocate ---------------------------------------------------------
+// Candidate lists, counters and thresholds live in one array that is part of the library's device image: every GPU
+// the library runs on holds its own copy (STATIC_BYTES, until the process ends) at its own address.  The name
+// `scratch` is only a handle in host code; the address the kernels get is looked up once per device with
+// hipGetSymbolAddress and kept in g_scratch_ptr.
+namespace {
+
+constexpr int STATIC_Q_MAX = 64;            // queries per call
+constexpr int STATIC_K_MAX = 1024;          // results per query
+constexpr int STATIC_CH_MAX = 32768;        // pool rows per chunk (the sweep above uses CH_MAX = 131072)
+constexpr int STATIC_CAP = 2 * STATIC_K_MAX + STATIC_CH_MAX;
+constexpr size_t STATIC_HEAD = 1024;        // counters [Q_MAX] u32, thresholds [Q_MAX] f32, padded
+constexpr size_t STATIC_BYTES = STATIC_HEAD + (size_t)STATIC_Q_MAX * STATIC_CAP * 8;
+constexpr int MAX_DEVICES = 64;
+
+static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
+
+void* g_scratch_ptr[MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;
+
+}  // namespace
+
+extern "C" size_t paced_pool_topk_static_bytes(void) { return STATIC_BYTES; }
+extern "C" int paced_pool_topk_static_max_queries(void) { return STATIC_Q_MAX; }
+extern "C" int paced_pool_topk_static_max_k(void) { return STATIC_K_MAX; }
+
+extern "C" int paced_pool_topk_static(const void* queries, const void* pool, int Q, long long Np, int D, int k,
+                                      long long index_base, float* out_scores, long long* out_idx, void* stream) {
+    PACED_CHECK_ARG(queries && pool && out_scores && out_idx, "paced_pool_topk_static: null operand");
+    PACED_CHECK_ARG(Q > 0 && Np > 0 && D > 0 && D % 64 == 0, "paced_pool_topk_static: need Q, Np > 0 and D a multiple of 64 (got %d, %lld, %d)", Q, Np, D);
+    PACED_CHECK_ARG(Q <= STATIC_Q_MAX, "paced_pool_topk_static: at most %d queries per call (got %d); use paced_pool_topk with a workspace", STATIC_Q_MAX, Q);
+    PACED_CHECK_ARG(k > 0 && k <= STATIC_K_MAX, "paced_pool_topk_static: k must be in [1, %d] (got %d); use paced_pool_topk with a workspace", STATIC_K_MAX, k);
+    PACED_CHECK_ARG(Np < 0xFFFFFFFFll, "paced_pool_topk_static: at most 2^32-1 pool rows per call (shard larger pools)");
+    PACED_CHECK_ARG(((uintptr_t)queries & 15) == 0 && ((uintptr_t)pool & 15) == 0, "paced_pool_topk_static: misaligned buffers");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        paced_set_error("paced_pool_topk_static: no current device (or device index above %d)", MAX_DEVICES - 1);
+        return PACED_ERR_HIP;
+    }
+    void* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void* ptr = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr) {
+                paced_set_error("paced_pool_topk_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+                return PACED_ERR_HIP;
+            }
+            g_scratch_ptr[dev] = ptr;
+        }
+        base = g_scratch_ptr[dev];
+    }
+    // every call starts from counters and thresholds written by topk_init_kernel; stale candidates beyond a
+    // query's counter are never read
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(base);
+    float* thr = reinterpret_cast<float*>(cnt + STATIC_Q_MAX);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(base) + STATIC_HEAD);
+    return pool_topk_sweep(queries, pool, Q, Np, D, k, index_base, out_scores, out_idx, cnt, thr, cand, STATIC_CAP, STATIC_CH_MAX,
+                           (hipStream_t)stream);
 }
 
 extern "C" int paced_topk_merge(const float* scores, const long long* idx, int Q, int total, int k,

@@ -376,6 +376,21 @@ def pool_topk(queries, pool, k, *, index_base=0, workspace=None):
     return scores, idx
 
 
+def pool_topk_static(queries, pool, k, out_scores, out_idx, *, index_base=0):
+    """``pool_topk`` into caller-provided outputs with the library's built-in candidate array instead of a workspace:
+    the call allocates nothing (limits: ``paced_pool_topk_static_max_queries()`` queries, ``..._max_k()`` results)."""
+    lib = _lib.load()
+    _chk(queries, BF16, "queries"); _chk(pool, BF16, "pool"); _chk(out_scores, F32, "out_scores"); _chk(out_idx, I64, "out_idx")
+    Q, D = queries.shape
+    if pool.dim() != 2 or pool.shape[1] != D or not (queries.is_contiguous() and pool.is_contiguous()):
+        raise ValueError("pool must be a contiguous [Np, D] matrix with the queries' D")
+    if tuple(out_scores.shape) != (Q, k) or tuple(out_idx.shape) != (Q, k) or not (out_scores.is_contiguous() and out_idx.is_contiguous()):
+        raise ValueError(f"outputs must be contiguous [{Q}, {k}]")
+    _lib.check(lib.paced_pool_topk_static(_p(queries), _p(pool), Q, pool.shape[0], D, k, index_base, _p(out_scores), _p(out_idx),
+                                          _stream()), "paced_pool_topk_static")
+    return out_scores, out_idx
+
+
 def topk_merge(scores, idx, k):
     lib = _lib.load()
     _chk(scores, F32, "scores"); _chk(idx, I64, "idx")
