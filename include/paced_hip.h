@@ -50,8 +50,9 @@ const char* paced_last_error(void);
  *   5  C(f32) += acc   (atomic; required when splits > 1)
  *   6  C(bf16) = bit(aux, m, n) ? acc * mask_scale : 0   backward of (2) given the byte matrix it wrote (N % 8 == 0,
  *                                                    ldaux >= N/8 bytes); reads 1/16 of what (3) reads
- * Requirements: K % 64 == 0 for a non-transposed operand; N % 4 == 0; lda, ldb % 8 == 0;
- * 16-byte aligned bases.  M, N and a transposed contraction length may be ragged. */
+ * Requirements: K % 64 == 0 for a non-transposed operand; N % 4 == 0 (N % 8 == 0 for a transposed B); lda, ldb % 8 == 0;
+ * 16-byte aligned bases.  M, N and a transposed contraction length may be ragged; a transposed A with M % 8 != 0
+ * needs lda >= M rounded up to 8 with every row of lda elements allocated (the padding is read, never used). */
 int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
                     int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
                     int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
@@ -150,9 +151,10 @@ int paced_cross2_fwd(const void* enc, int ld, const void* qk, void* z, float* ls
 /* Backward of paced_cross2_fwd given dz [N][C][d]: dqk [N][C][d], and the factors of the encoder-state gradient
  *   d enc[n][k] = sum_c ds[c][k] qk[c] + dropout(p)[c][k] dz[c]
  * written for a later token-contraction product over all decoder layers: wslot + n*wstride holds ds then
- * dropout(p), [2C][S] bf16; uslot + n*ustride holds qk then dz, [2C][d] bf16 (strides in elements). */
+ * dropout(p), [2C][wld] bf16 (wld >= S, a multiple of 4; columns S..wld-1 are not written); uslot + n*ustride
+ * holds qk then dz, [2C][d] bf16 (strides in elements). */
 int paced_cross2_bwd(const void* enc, int ld, const void* qk, const void* dz, const void* z, const float* lse,
-                     void* dqk, void* wslot, long long wstride, void* uslot, long long ustride,
+                     void* dqk, void* wslot, long long wstride, int wld, void* uslot, long long ustride,
                      int N, int S, int H, int d, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ---- loss: nn.CrossEntropyLoss(ignore_index, reduction='none'), lceT5.py:110,117-118 ----------

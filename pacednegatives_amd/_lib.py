@@ -39,7 +39,7 @@ SIGNATURES = {
     "paced_dec_self_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _u32, _vp]),
     "paced_cross_attn_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _u32, _vp]),
     "paced_cross2_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u32, _vp]),
-    "paced_cross2_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i, _i, _i, _i, _f, _u32, _vp]),
+    "paced_cross2_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _ll, _i, _i, _i, _i, _f, _u32, _vp]),
     "paced_cross_attn_bwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp]),
     "paced_cross_entropy": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _ll, _f, _vp]),
     "paced_lce_group": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -767,7 +767,7 @@ struct CrossArgs {
     bf16* z;                        // forward output
     bf16* dqk;                      // [N, C, d]   (backward output)
     float* lse;                     // [N, C]
-    bf16* wslot; long long wstride; // backward: ds rows then dropped-p rows, [2C][S] per sequence, sequence stride in elements
+    bf16* wslot; long long wstride; int wld;   // backward: ds rows then dropped-p rows, [2C][wld] per sequence (wld >= S), sequence stride in elements
     bf16* uslot; long long ustride; // backward: copies of qk then dz, [2C][d] per sequence
     int N, S, C, d;
     DropCfg drop;
@@ -935,8 +935,8 @@ __global__ void __launch_bounds__(256, NF <= 1 ? 2 : 1) cross2_bwd_kernel(CrossA
 #pragma unroll
         for (int r = 0; r < 16; ++r) { qacc[f][0][r] = 0.f; qacc[f][1][r] = 0.f; }
     const uint64_t dbase = ((uint64_t)n * C + cc) * (uint64_t)((S + 3) & ~3);
-    const bool quad_ok = (S & 3) == 0;
-    bf16* wrow = a.wslot + (size_t)n * a.wstride + (size_t)cc * S;
+    const int wld = a.wld;                                      // a multiple of 4: every quad of a row is 8-byte aligned
+    bf16* wrow = a.wslot + (size_t)n * a.wstride + (size_t)cc * wld;
 
     const int ntile = (S + 31) / 32;
     for (int kt = 0; kt < ntile; ++kt) {
@@ -978,13 +978,13 @@ __global__ void __launch_bounds__(256, NF <= 1 ? 2 : 1) cross2_bwd_kernel(CrossA
                 pdv[e] = f2bf(pd[r + e]);
             }
             if (w == 0 && c < C) {
-                if (quad_ok && key + 3 < S) {
+                if (key + 3 < S) {
                     *reinterpret_cast<bf16x4*>(wrow + key) = dsv;
-                    *reinterpret_cast<bf16x4*>(wrow + (size_t)C * S + key) = pdv;
+                    *reinterpret_cast<bf16x4*>(wrow + (size_t)C * wld + key) = pdv;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (key + e < S) { wrow[key + e] = dsv[e]; wrow[(size_t)C * S + key + e] = pdv[e]; }
+                        if (key + e < S) { wrow[key + e] = dsv[e]; wrow[(size_t)C * wld + key + e] = pdv[e]; }
                 }
             }
         }
@@ -1158,19 +1158,20 @@ extern "C" int paced_cross2_fwd(const void* enc, int ld, const void* qk, void* z
 }
 
 extern "C" int paced_cross2_bwd(const void* enc, int ld, const void* qk, const void* dz, const void* z, const float* lse,
-                                void* dqk, void* wslot, long long wstride, void* uslot, long long ustride,
+                                void* dqk, void* wslot, long long wstride, int wld, void* uslot, long long ustride,
                                 int N, int S, int H, int d, float drop_p, uint32_t drop_seed, void* stream) {
     if (int e = check_cross2("paced_cross2_bwd", N, S, H, d)) return e;
     PACED_CHECK_ARG(enc && qk && dz && z && lse && dqk && wslot && uslot, "paced_cross2_bwd: null operand");
     PACED_CHECK_ARG(ld % 8 == 0 && ld >= d, "paced_cross2_bwd: the row stride of enc must be a multiple of 8 and >= d");
-    PACED_CHECK_ARG(wstride >= (long long)4 * H * S && ustride >= (long long)4 * H * d && ustride % 8 == 0,
+    PACED_CHECK_ARG(wld >= S && wld % 4 == 0, "paced_cross2_bwd: the row stride of the score factors must be a multiple of 4 and >= S (got %d, S=%d)", wld, S);
+    PACED_CHECK_ARG(wstride >= (long long)4 * H * wld && ustride >= (long long)4 * H * d && ustride % 8 == 0,
                     "paced_cross2_bwd: per-sequence strides of the factor buffers are too small");
-    PACED_CHECK_ARG(((uintptr_t)uslot & 15) == 0 && ((uintptr_t)wslot & 7) == 0 && (S % 4 != 0 || wstride % 4 == 0),
+    PACED_CHECK_ARG(((uintptr_t)uslot & 15) == 0 && ((uintptr_t)wslot & 7) == 0 && wstride % 4 == 0,
                     "paced_cross2_bwd: factor buffers are misaligned");
     CrossArgs a = {};
     a.enc = (const bf16*)enc; a.ld = ld; a.qk = (const bf16*)qk; a.dz = (const bf16*)dz; a.z_in = (const bf16*)z;
     a.lse = const_cast<float*>(lse); a.dqk = (bf16*)dqk;
-    a.wslot = (bf16*)wslot; a.wstride = wstride; a.uslot = (bf16*)uslot; a.ustride = ustride;
+    a.wslot = (bf16*)wslot; a.wstride = wstride; a.wld = wld; a.uslot = (bf16*)uslot; a.ustride = ustride;
     a.N = N; a.S = S; a.C = 2 * H; a.d = d; a.drop = make_drop(drop_p, drop_seed);
     const int smem = (d / 64) * 4096 + 16384 + 512;
     switch ((d / 64 + 3) / 4) {

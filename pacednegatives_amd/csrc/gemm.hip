@@ -239,7 +239,9 @@ __device__ __forceinline__ WorkItem decode_item(const GemmParams& p, int L, int 
     const int rowsA = min(BM, p.M - it.m0), rowsB = min(BN, p.N - it.n0);
     const bf16* baseA = p.A + (long long)it.b * p.strideA + (TA ? (size_t)it.m0 : (size_t)it.m0 * p.lda);
     const bf16* baseB = p.B + (long long)it.b * p.strideB + (TB ? (size_t)it.n0 : (size_t)it.n0 * p.ldb);
-    const uint32_t recA = TA ? (uint32_t)(((size_t)(p.K - 1) * p.lda + rowsA) * 2) : (uint32_t)(((size_t)(rowsA - 1) * p.lda + p.K) * 2);
+    // (a transposed A whose M is not a multiple of 8: the last 16-byte piece of a contraction row straddles M; it is kept
+    // in range, lda >= M rounded up to 8 guarantees the bytes exist, and the output rows >= M it feeds are never stored)
+    const uint32_t recA = TA ? (uint32_t)(((size_t)(p.K - 1) * p.lda + ((rowsA + 7) & ~7)) * 2) : (uint32_t)(((size_t)(rowsA - 1) * p.lda + p.K) * 2);
     const uint32_t recB = TB ? (uint32_t)(((size_t)(p.K - 1) * p.ldb + rowsB) * 2) : (uint32_t)(((size_t)(rowsB - 1) * p.ldb + p.K) * 2);
     it.rA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, recA, 0x00020000);
     it.rB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, recB, 0x00020000);
@@ -1062,7 +1064,8 @@ static int gemm_entry(const void* A, const void* B, void* C, const void* aux,
                     "paced_gemm_bf16: operands must be 16-byte aligned");
     if (!trans_a) PACED_CHECK_ARG(K % 64 == 0, "paced_gemm_bf16: K must be a multiple of 64 for a K-contiguous A");
     if (!trans_b) PACED_CHECK_ARG(K % 64 == 0, "paced_gemm_bf16: K must be a multiple of 64 for a K-contiguous B");
-    if (trans_a) PACED_CHECK_ARG((size_t)K * lda * 2 < 0xFFFFFFF0ull && M % 8 == 0, "paced_gemm_bf16: transposed A too large for 32-bit offsets or M%%8");
+    if (trans_a) PACED_CHECK_ARG((size_t)K * lda * 2 < 0xFFFFFFF0ull && lda >= ((M + 7) & ~7),
+                                 "paced_gemm_bf16: transposed A too large for 32-bit offsets, or lda below M rounded up to a multiple of 8");
     if (trans_b) PACED_CHECK_ARG((size_t)K * ldb * 2 < 0xFFFFFFF0ull && N % 8 == 0, "paced_gemm_bf16: transposed B too large for 32-bit offsets or N%%8");
     if (!trans_a) PACED_CHECK_ARG((size_t)128 * lda * 2 < 0x7FFFFFFFull, "paced_gemm_bf16: lda too large");
     if (!trans_b) PACED_CHECK_ARG((size_t)128 * ldb * 2 < 0x7FFFFFFFull, "paced_gemm_bf16: ldb too large");

@@ -285,8 +285,11 @@ def cross2_fwd(enc, qk, z, lse, N, S, H, *, drop_p=0.0, drop_seed=0):
     return z
 
 
-def cross2_bwd(enc, qk, dz, z, lse, dqk, wslot, wstride, uslot, ustride, N, S, H, *, drop_p=0.0, drop_seed=0):
-    """Backward of cross2_fwd; wslot/uslot are views whose first element is this layer's slot of the factor buffers."""
+def cross2_bwd(enc, qk, dz, z, lse, dqk, wslot, wstride, uslot, ustride, N, S, H, *, wld=None, drop_p=0.0, drop_seed=0):
+    """Backward of cross2_fwd; wslot/uslot are views whose first element is this layer's slot of the factor buffers;
+    ``wld`` is the row stride of the [2C][wld] score factors (default S; S rounded up to a multiple of 8 lets the
+    factors feed the token-contraction product for any S)."""
+    wld = S if wld is None else wld
     lib = _lib.load()
     for t, n in ((enc, "enc"), (qk, "qk"), (dz, "dz"), (z, "z"), (dqk, "dqk"), (wslot, "wslot"), (uslot, "uslot")):
         _chk(t, BF16, n)
@@ -294,7 +297,7 @@ def cross2_bwd(enc, qk, dz, z, lse, dqk, wslot, wstride, uslot, ustride, N, S, H
     d = enc.shape[1]
     for t in (qk, dz, z, dqk):
         assert tuple(t.shape) == (N * 2, H * d) and t.is_contiguous()
-    _lib.check(lib.paced_cross2_bwd(_p(enc), _rows2d(enc, "enc"), _p(qk), _p(dz), _p(z), _p(lse), _p(dqk), _p(wslot), wstride,
+    _lib.check(lib.paced_cross2_bwd(_p(enc), _rows2d(enc, "enc"), _p(qk), _p(dz), _p(z), _p(lse), _p(dqk), _p(wslot), wstride, wld,
                                     _p(uslot), ustride, N, S, H, d, drop_p, drop_seed, _stream()), "paced_cross2_bwd")
 
 

@@ -35,7 +35,8 @@ class MonoT5Model:
     def init(name_or_dir: str = "t5-base", device="cuda"):
         from .model import T5ForConditionalGenerationHIP
         from .tokenizer import load_tokenizer
-        return MonoT5Model(T5ForConditionalGenerationHIP.from_pretrained(name_or_dir, device=device), load_tokenizer(name_or_dir))
+        model = T5ForConditionalGenerationHIP.from_pretrained(name_or_dir, device=device)
+        return MonoT5Model(model, load_tokenizer(name_or_dir, model.config.vocab_size))
 
     def save_pretrained(self, path):
         self.model.save_pretrained(path)

@@ -149,10 +149,10 @@ class T5Engine:
         return _mix(st.seed, site + 16 * layer + (4096 if dec else 0))
 
     def _cross2_ok(self, S: int) -> bool:
-        """The projection-free cross-attention kernels need 2H <= 32 queries per sequence, d_model a multiple of 64 up to
-        1024 and (for the token-contraction product of the backward) S a multiple of 8; other shapes take the K/V path."""
+        """The projection-free cross-attention kernels need 2H <= 32 queries per sequence and d_model a multiple of 64 up
+        to 1024; any sequence length (batches are padded to their longest sequence); other shapes take the K/V path."""
         dm = self.dims
-        return (2 * dm.num_heads <= 32 and dm.d_model % 64 == 0 and dm.d_model <= 1024 and S % 8 == 0
+        return (2 * dm.num_heads <= 32 and dm.d_model % 64 == 0 and dm.d_model <= 1024
                 and dm.inner == dm.num_heads * 64 and not self.force_kv_projection)
 
     def _empty(self, rows, cols, dtype=BF16):
@@ -367,8 +367,9 @@ class T5Engine:
             if st.cross2:
                 Wckv, gckv = P.w(pre + "ckv"), P.grad(pre + "ckv")
                 C2 = 2 * H
-                if xW is None:      # factors of d enc over all decoder layers: [N][nd*2C][S] and [N][nd*2C][d]
-                    xW = torch.empty(N, nd * 2 * C2, S, dtype=BF16, device=self.device)
+                if xW is None:      # factors of d enc over all decoder layers: [N][nd*2C][S8] and [N][nd*2C][d]
+                    S8 = (S + 7) // 8 * 8       # row stride the token-contraction product below can read; S columns are used
+                    xW = torch.empty(N, nd * 2 * C2, S8, dtype=BF16, device=self.device)
                     xU = torch.empty(N, nd * 2 * C2, d, dtype=BF16, device=self.device)
                 # dWv_h += dcctx_h^T z_h ;  dz_h = dcctx_h Wv_h
                 K.gemm_batched(dcctx, sv.z, gckv[I:], M=dk, N=d, K=Md, lda=I, ldb=H * d, ldc=d, batch=H,
@@ -376,8 +377,8 @@ class T5Engine:
                 dzz, dqk = self._empty(Md, H * d), self._empty(Md, H * d)
                 K.gemm_batched(dcctx, Wckv[I:], dzz, M=Md, N=d, K=dk, lda=I, ldb=d, ldc=H * d, batch=H,
                                stride_a=dk, stride_b=dk * d, stride_c=d, trans_b=True)
-                K.cross2_bwd(st.enc_out, sv.qk, dzz, sv.z, sv.clse, dqk, xW[0, l * 2 * C2:], nd * 2 * C2 * S,
-                             xU[0, l * 2 * C2:], nd * 2 * C2 * d, N, S, H, drop_p=p, drop_seed=self._seed(st, _SITE_CATT, l, True))
+                K.cross2_bwd(st.enc_out, sv.qk, dzz, sv.z, sv.clse, dqk, xW[0, l * 2 * C2:], nd * 2 * C2 * S8,
+                             xU[0, l * 2 * C2:], nd * 2 * C2 * d, N, S, H, wld=S8, drop_p=p, drop_seed=self._seed(st, _SITE_CATT, l, True))
                 # dq_h = dqk_h Wk_h^T ;  dWk_h += q_h^T dqk_h
                 K.gemm_batched(dqk, Wckv[:I], dqc, M=Md, N=dk, K=d, lda=H * d, ldb=d, ldc=I, batch=H,
                                stride_a=d, stride_b=dk * d, stride_c=dk)
@@ -422,8 +423,8 @@ class T5Engine:
             # d enc[n] = sum over layers and projected queries of ds (x) qk + dropout(p) (x) dz: one token-contraction product
             Kc = nd * 4 * H
             d_enc = self._empty(M, d)
-            K.gemm_batched(xW, xU, d_enc, M=S, N=d, K=Kc, lda=S, ldb=d, ldc=d, batch=N,
-                           stride_a=Kc * S, stride_b=Kc * d, stride_c=S * d, trans_a=True, trans_b=True)
+            K.gemm_batched(xW, xU, d_enc, M=S, N=d, K=Kc, lda=S8, ldb=d, ldc=d, batch=N,
+                           stride_a=Kc * S8, stride_b=Kc * d, stride_c=S * d, trans_a=True, trans_b=True)
             del xW, xU
 
         # ---- encoder

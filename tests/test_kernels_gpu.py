@@ -58,6 +58,24 @@ def test_gemm_exact_integers(M, N, K_, ta, tb, tile):
     assert torch.equal(c.cpu(), want)
 
 
+@pytest.mark.parametrize("M,N,K_", [(101, 136, 96), (250, 768, 200), (3, 8, 40), (515, 256, 129)])
+def test_gemm_transposed_a_with_ragged_rows_exact(M, N, K_, tile):
+    """A stored [K][M] with M not a multiple of 8: rows padded to a multiple of 8 elements.  The padding is read with the
+    last 16-byte piece of every contraction row but only feeds output rows >= M, which are never stored: NaN padding
+    must leave the result exact.  (The token-contraction product of the decoder cross-attention's backward has M = the
+    sequence length, which is arbitrary.)"""
+    M8 = (M + 7) // 8 * 8
+    a, b = ints((K_, M), -3, 3, 5), ints((K_, N), -3, 3, 6)
+    A = torch.full((K_, M8), float("nan"), device=DEV, dtype=torch.bfloat16)
+    A[:, :M] = a.to(DEV).to(torch.bfloat16)
+    c = torch.full((M, N), float("nan"), device=DEV)
+    K.gemm(A[:, :M], bf(b), c, trans_a=True, trans_b=True, epilogue=K.EPI_F32)
+    assert torch.equal(c.cpu(), a.t() @ b)
+    c16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    K.gemm(A[:, :M], bf(b), c16, trans_a=True, trans_b=True)
+    assert torch.equal(c16.float().cpu(), (a.t() @ b).to(torch.bfloat16).float())
+
+
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_many_tiles_per_workgroup_exact(ta, tb, tile):
     """More output tiles than compute units: every persistent workgroup walks several work items, the
@@ -510,13 +528,15 @@ def test_cross_attention_without_kv_projection(N, S, H, d, p):
     zr.backward(dz.float().view(N, C, d))
     dqk = torch.empty_like(qk)
     L, l = 2, 1                                                    # this call fills layer slot 1 of 2
-    W = torch.full((N, L * 2 * C, S), float("nan"), device=DEV, dtype=torch.bfloat16)
+    S8 = (S + 7) // 8 * 8                                          # row stride of the score factors (any S)
+    W = torch.full((N, L * 2 * C, S8), float("nan"), device=DEV, dtype=torch.bfloat16)
     U = torch.full((N, L * 2 * C, d), float("nan"), device=DEV, dtype=torch.bfloat16)
-    K.cross2_bwd(enc, qk, dz, z, lse, dqk, W[0, l * 2 * C:], L * 2 * C * S, U[0, l * 2 * C:], L * 2 * C * d, N, S, H,
-                 drop_p=p, drop_seed=9)
+    K.cross2_bwd(enc, qk, dz, z, lse, dqk, W[0, l * 2 * C:], L * 2 * C * S8, U[0, l * 2 * C:], L * 2 * C * d, N, S, H,
+                 wld=S8, drop_p=p, drop_seed=9)
     assert (dqk.float() - ql.grad).abs().max().item() < 1.5e-2 * ql.grad.abs().max().item()
     assert torch.isnan(W[:, :2 * C].float()).all() and torch.isnan(U[:, :2 * C].float()).all()      # other slots untouched
-    Wl, Ul = W[:, 2 * C:].float(), U[:, 2 * C:].float()
+    assert torch.isnan(W[:, 2 * C:, S:].float()).all()             # columns past S are left alone
+    Wl, Ul = W[:, 2 * C:, :S].float(), U[:, 2 * C:].float()
     assert torch.equal(Ul[:, :C], qk.float().view(N, C, d)) and torch.equal(Ul[:, C:], dz.float().view(N, C, d))
     de = torch.einsum("nks,nkd->nsd", Wl, Ul).reshape(N * S, d)    # the product the engine takes over all layers
     assert (de - el.grad).abs().max().item() < 2e-2 * el.grad.abs().max().item()
