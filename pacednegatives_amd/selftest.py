@@ -42,8 +42,8 @@ def smoke_step(verbose: bool = True):
     eta_err = abs(model.difficulty - float(eta))
     if verbose:
         print(f"[smoke] LCE rows HIP {got.tolist()} oracle {ref['loss'].tolist()} rel err {err:.2e}; eta HIP {model.difficulty:.6f} oracle {float(eta):.6f}")
-    # bf16 storage on both sides, different accumulation order: 1e-2 of the loss scale
-    assert err < 1e-2, f"LCE loss rows differ from the oracle by {err}"
+    # bf16 rounding at the same points on both sides, different accumulation order: measured 4.4e-4 of the loss scale
+    assert err < 2e-3, f"LCE loss rows differ from the oracle by {err}"
     assert eta_err < 1e-4, f"eta after the meta step differs by {eta_err}"
     w = model.model.params.master("enc.0.wi").cpu()
     w_ref = P["encoder.block.0.layer.1.DenseReluDense.wi.weight"]

@@ -2,7 +2,7 @@
 fixtures recorded from Hugging Face T5 / the reference.  Tolerances: the HIP path stores activations
 in bf16 (8 significant bits); against the oracle run with bf16 rounding at the same points the
 difference is accumulation order only (1e-3-class); against the fp32 fixtures it is the bf16 storage
-error itself (a few 1e-2 of the logit scale)."""
+error itself (5e-3 of the logit scale at these depths)."""
 import math
 import os
 import warnings
@@ -18,9 +18,11 @@ from oracle.t5_ref import T5Dims as RefDims, init_params, t5_forward  # noqa: E4
 from pacednegatives_amd.config import NAMED  # noqa: E402
 
 # Bounds, each about twice the largest value measured on an MI355X (``pytest -s`` prints the measurements).
-B_LOGITS_EMU, B_LOGITS_HF = 6e-3, 5e-2          # logits, relative to the largest logit
-B_LOSS_EMU, B_LOSS_HF = 2e-3, 1e-2              # per-token / per-row losses, relative
-B_ROWS_EMU, B_ROWS_HF = 5e-3, 2e-2              # LCE rows of a training step
+# "emu" = against the oracle with bf16 rounding at the engine's storage points (what differs is summation order),
+# "hf" = against fixtures recorded in fp32 from Hugging Face T5 / the reference (what differs is bf16 storage itself).
+B_LOGITS_EMU, B_LOGITS_HF = 6e-3, 1e-2          # logits, relative to the largest logit      (measured 4.9e-3, 4.6e-3)
+B_LOSS_EMU, B_LOSS_HF = 2e-3, 3e-3              # per-token losses, relative                 (measured 9.2e-4, 1.6e-3)
+B_ROWS_EMU, B_ROWS_HF = 2.5e-3, 5e-3            # LCE rows of training steps 0-2, relative    (measured 1.4e-3, 2.3e-3; step 0: 3e-4)
 TINY = NAMED["t5-tiny"]
 RTINY = RefDims(TINY.vocab_size, TINY.d_model, TINY.d_kv, TINY.num_heads, TINY.d_ff, TINY.num_layers, TINY.num_decoder_layers)
 
@@ -85,10 +87,10 @@ def test_monot5_score_vs_hf_fixture_and_oracle(golden_dir, ci):
     # a difference of two logits: twice the logit bound of the forward test (6e-3 x scale, scale ~ 1) against the
     # oracle with bf16 rounding at the same points, 3e-2 against the Hugging Face fp32 logits (bf16 storage error)
     within("monoT5 score vs bf16-emulating oracle (abs.)", (got - emu).abs().max().item(), 1.2e-2)
-    within("monoT5 score vs Hugging Face fp32 (abs.)", (got - hf).abs().max().item(), 3e-2)
+    within("monoT5 score vs Hugging Face fp32 (abs.)", (got - hf).abs().max().item(), 1.5e-2)
     # the generated labels do not matter at position 0: same scores as the full-head path with other labels
     full = m(input_ids=ids, labels=torch.tensor([[6136, 1]] * ids.shape[0])).logits.cpu()
-    within("monoT5 two-row head vs full head (abs.)", (got - ref(full)).abs().max().item(), 2e-3)
+    within("monoT5 two-row head vs full head (abs.)", (got - ref(full)).abs().max().item(), 2e-6)
 
 
 def test_forward_is_batch_invariant():
