@@ -34,27 +34,28 @@ RND = 42
 F32, BF16 = torch.float32, torch.bfloat16
 
 
+def linear_warmup_multiplier(step, num_warmup_steps, num_training_steps):
+    """The linear warm-up / linear decay factor both schedules of this package use (``lceT5.LinearWarmupSchedule``)."""
+    sched = LinearWarmupSchedule.__new__(LinearWarmupSchedule)
+    sched.warm, sched.total = num_warmup_steps, num_training_steps
+    return sched.multiplier(step)
+
+
 def adjust_lr(optimizer, init_lr, num_warmup_steps, num_training_steps):
-    """Reference ``pairwrapper.py:16-25``."""
+    """``update(step)`` sets every parameter group's lr to init_lr x the linear warm-up factor (same contract as the
+    reference's ``pairwrapper.adjust_lr``, ``pairwrapper.py:16-25``)."""
     def update(step):
-        if step < num_warmup_steps:
-            lr = init_lr * float(step) / float(max(1, num_warmup_steps))
-        else:
-            lr = init_lr * max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
-        for param_group in optimizer.param_groups:
-            param_group["lr"] = lr
+        lr = init_lr * linear_warmup_multiplier(step, num_warmup_steps, num_training_steps)
+        for group in optimizer.param_groups:
+            group["lr"] = lr
     return update
 
 
 def interpolate_scalar(start_value, end_value, num_steps):
-    """Reference ``old/interp.py:10-18``."""
-    step_size = (end_value - start_value) / num_steps
-
-    def get_interpolated_value(step):
-        if step > num_steps:
-            return end_value
-        return start_value + step * step_size
-    return get_interpolated_value
+    """Pace that moves linearly from ``start_value`` to ``end_value`` over ``num_steps`` steps and stays there
+    (contract of the reference's ``old/interp.py:10-18``)."""
+    slope = (end_value - start_value) / num_steps
+    return lambda step: end_value if step > num_steps else start_value + step * slope
 
 
 class PacedWrapper:

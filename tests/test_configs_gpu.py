@@ -211,3 +211,50 @@ def test_monot5_factory_scores_a_tokenised_batch():
     s = scorer({"input_ids": enc["input_ids"]})
     assert s.shape == (2,) and torch.isfinite(s).all() and (s < 0).all()
     assert (scorer.rel, scorer.nrel) == (1176, 6136)
+
+
+# ---- checkpoint directories either side of the path (train/train_lce.py:103, eval.py:23) ----------------------
+def test_loads_a_checkpoint_written_by_hugging_face(golden_dir):
+    """tests/golden/hf_ckpt was written by T5ForConditionalGeneration.save_pretrained (tools/make_golden_hf_ckpt.py)."""
+    from pacednegatives_amd.model import T5ForConditionalGenerationHIP
+    from test_engine_gpu import B_LOGITS_HF
+    g = np.load(os.path.join(golden_dir, "hf_ckpt_logits.npz"))
+    m = T5ForConditionalGenerationHIP.from_pretrained(os.path.join(golden_dir, "hf_ckpt"))
+    m.eval()
+    assert (m.config.d_model, m.config.num_heads, m.config.vocab_size, m.config.dropout_rate) == (64, 2, 6144, 0.1)
+    got = m(input_ids=torch.from_numpy(g["ids"]), labels=torch.from_numpy(g["labels"])).logits.cpu()
+    within("logits of a Hugging Face-written checkpoint vs its fp32 logits", relerr(got, g["logits"]), B_LOGITS_HF)
+
+
+def test_hugging_face_loads_what_save_pretrained_writes(golden_dir, tmp_path):
+    """Same tensor names, shapes and dtype as the Hugging Face-written fixture; transformers loads the directory with no
+    missing or unexpected keys and computes the same logits (what MonoT5ReRanker(model=dir) in eval.py:23 relies on)."""
+    from safetensors import safe_open
+    from pacednegatives_amd.model import T5ForConditionalGenerationHIP
+    from test_engine_gpu import B_LOGITS_HF
+    src = os.path.join(golden_dir, "hf_ckpt")
+    m = T5ForConditionalGenerationHIP.from_pretrained(src)
+    out = str(tmp_path / "finalmodel")
+    m.save_pretrained(out)
+    with safe_open(os.path.join(src, "model.safetensors"), "pt") as fa, safe_open(os.path.join(out, "model.safetensors"), "pt") as fb:
+        assert set(fa.keys()) == set(fb.keys())
+        assert fb.metadata() == {"format": "pt"}
+        for k in fa.keys():
+            a, b = fa.get_tensor(k), fb.get_tensor(k)
+            assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b), k       # fp32 master copy: a lossless round trip
+    import json
+    ca, cb = json.load(open(os.path.join(src, "config.json"))), json.load(open(os.path.join(out, "config.json")))
+    for key in ("architectures", "model_type", "vocab_size", "d_model", "d_kv", "d_ff", "num_layers", "num_decoder_layers", "num_heads",
+                "relative_attention_num_buckets", "relative_attention_max_distance", "dropout_rate", "layer_norm_epsilon",
+                "feed_forward_proj", "is_encoder_decoder", "tie_word_embeddings", "pad_token_id", "eos_token_id", "decoder_start_token_id"):
+        assert ca[key] == cb[key], key
+    from transformers import T5ForConditionalGeneration
+    hf, info = T5ForConditionalGeneration.from_pretrained(out, output_loading_info=True)
+    assert not info["missing_keys"] and not info["unexpected_keys"] and not info.get("mismatched_keys"), info
+    g = np.load(os.path.join(golden_dir, "hf_ckpt_logits.npz"))
+    ids, labels = torch.from_numpy(g["ids"]), torch.from_numpy(g["labels"])
+    with torch.no_grad():
+        want = hf.eval()(input_ids=ids, labels=labels).logits
+    assert torch.equal(want, torch.from_numpy(g["logits"])) or relerr(want, g["logits"]) < 1e-5
+    m.eval()
+    within("this package vs transformers on the directory this package wrote", relerr(m(input_ids=ids, labels=labels).logits.cpu(), want), B_LOGITS_HF)

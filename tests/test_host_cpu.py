@@ -225,3 +225,19 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpaced_hip.so")
     with pytest.raises(_lib.PacedHipError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_reference_import_line_resolves_to_this_package():
+    """train/train_lce.py:4 of the reference, unedited, and the other public modules under the reference's package name."""
+    from pacednegatives.lceT5 import LCEModel, LCEDataModule, ChangeDifficulty
+    import pacednegatives.dataloader as dl
+    import pacednegatives.weights as wt
+    import pacednegatives.pairwrapper as pw
+    import pacednegatives_amd.lceT5 as impl
+    assert LCEModel is impl.LCEModel and LCEDataModule is impl.LCEDataModule and ChangeDifficulty is impl.ChangeDifficulty
+    for name in ("LCEDataset", "TripletDataset", "PairLoader", "LevelLoader", "TripletLoader"):
+        assert hasattr(dl, name), name
+    for name in ("EtaWeights", "LCEWeights", "Weights"):
+        assert hasattr(wt, name), name
+    for name in ("PacedWrapper", "StdWrapper", "NewWrapper", "adjust_lr"):
+        assert hasattr(pw, name), name
