@@ -92,7 +92,7 @@ def run_train(args, rank, world, device):
         s = by_sym.setdefault(key, [0.0, 0.0, 0])
         s[0] += flops; s[1] += ms * 1e-3; s[2] += 1
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")      # rocprofv3 --pmc passes of this same command
+    tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")      # rocprofv3 --pmc passes of this same command
     if os.path.exists(tpath) and (args.model, B, nneg, S) == ("t5-base", 32, 16, 256):
         try:
             traffic = json.load(open(tpath))["gemm_phased_kernel"]["hbm_bytes_per_launch"]
@@ -111,7 +111,7 @@ def run_train(args, rank, world, device):
         dom = max(phased, key=lambda kv: kv[1][1])
         roof = {"bound": "mfma", "kernel": "gemm_phased_kernel (every launch of one training step)", "achieved": tot_f / tot_t / 1e12,
                 "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s", "frac": tot_f / tot_t / BF16_DENSE_PEAK, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; profiles/r1_pmc_traffic.json)",
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; profiles/r2_pmc_traffic.json)",
                 "flops_per_launch": tot_f / tot_n, "launches": tot_n, "avg_launch_us": tot_t / tot_n * 1e6,
                 "largest_share_variant": {"trans_a,trans_b,epilogue": list(dom[0][:3]), "TFLOP/s": dom[1][0] / dom[1][1] / 1e12,
                                     "launches": dom[1][2], "avg_launch_us": dom[1][1] / dom[1][2] * 1e6},
@@ -167,6 +167,28 @@ def cpu_baseline(args, dims):
                       f"{args.model} dims, fp32, dropout 0, torch CPU"}
 
 
+def cpu_baseline_mining(pool_rows, queries, k, budget_s=20.0):
+    """The negative-pool selection on the host cores: fp32 ``torch.matmul`` of 64-query chunks against a 1 M-row slice
+    of the same pool, ``torch.topk`` per chunk, until ``budget_s`` seconds are used; scores/s over the chunks finished."""
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    pool = pool_rows.float().cpu()
+    q = queries.float().cpu()
+    done, used = 0, 0.0
+    for lo in range(0, q.shape[0], 64):
+        t0 = time.perf_counter()
+        sc = q[lo:lo + 64] @ pool.t()
+        torch.topk(sc, min(k, pool.shape[0]), dim=1)
+        dt = time.perf_counter() - t0
+        if lo > 0:                   # the first chunk warms the thread pool up
+            used += dt; done += sc.shape[0]
+        if used > budget_s:
+            break
+    return {"value": done * pool.shape[0] / used, "unit": "scores/s", "cores": threads, "kind": "port",
+            "sample": f"{done} queries (chunks of 64, after one warm-up chunk) x {pool.shape[0]} pool rows x {pool.shape[1]} dims: "
+                      f"fp32 torch.matmul + torch.topk({k}) on the host, {used:.1f} s"}
+
+
 def run_mining(args, rank, world, device):
     """Secondary figure: pool rows are sharded over ranks, queries replicated, shard results merged."""
     from pacednegatives_amd import kernels as K, mining
@@ -203,11 +225,28 @@ def run_mining(args, rank, world, device):
     total_rows = Np * world
     flops = 2.0 * Q * total_rows * D
     bytes_alg = total_rows * D * 2 + Q * D * 2 + Q * k * 12
-    return {"metric": "negative-pool scores/sec", "value": Q * total_rows / el, "unit": "scores/s", "ms_per_sweep": el * 1e3,
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic_mining.json")     # rocprofv3 --pmc passes of tools/mine_once.py
+    if os.path.exists(tpath) and (Q, total_rows, k, world) == (4096, 10_000_000, 1000, 1):
+        try:
+            traffic = json.load(open(tpath))["sweep"]["hbm_bytes_per_sweep"]
+        except Exception:
+            traffic = None
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_mining(pool[:min(Np, 1_000_000)], queries, k)
+    # MFMA binds: all Q queries share one pass over the pool, so the intensity is Q FLOP per pool byte (4096 at the
+    # benchmark shape) against a ridge of peak FLOP/s / peak B/s = 312; HBM would bind for fewer than ~312 queries per pass.
+    out = {"metric": "negative-pool scores/sec", "value": Q * total_rows / el, "unit": "scores/s", "ms_per_sweep": el * 1e3,
             "config": {"workload": f"top-{k} of {Q} queries x {total_rows} pool rows x {D} dims, bf16, pool sharded over {world} GPU(s)"},
             "roofline": {"bound": "mfma", "achieved": flops / el / 1e12, "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": flops / el / (world * BF16_DENSE_PEAK), "hbm_frac": bytes_alg / el / (world * HBM_PEAK),
-                         "algorithmic_bytes": bytes_alg, "traffic": None}}
+                         "algorithmic_bytes": bytes_alg, "traffic": traffic,
+                         "binding": f"mfma: {Q} FLOP per pool byte against a ridge of {BF16_DENSE_PEAK / HBM_PEAK:.0f}; "
+                                    "HBM binds below that many queries per pass"}}
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
 
 
 def launch_ranks(n: int) -> int:

@@ -320,8 +320,11 @@ class LCEModel:
         R = 2 * B
         g_pos = 1.0 / R
         g_neg = (1.0 / R) * ((1.0 / nneg) if use_mean else 1.0)
-        if self.share_forward and self.dropout == 0.0:
-            raise NotImplementedError("share_forward (one forward serving both passes when dropout is off) is not implemented")
+        # share_forward: with dropout off the no-grad forwards (a) and the forwards that keep state (d) see the same
+        # parameters (only eta changes in between) and compute the same logits, so (d)'s loss rows serve (a) as well.
+        share = self.share_forward
+        if share and self.dropout != 0.0:
+            raise ValueError("share_forward needs dropout 0: with dropout on, the reference's two passes draw different masks")
 
         def no_grad_rows():
             """(a) no-grad forwards and the LCE rows                                        :131-135"""
@@ -365,7 +368,12 @@ class LCEModel:
             K.lce_group(pce2, nce2, rows, nneg, use_mean)
             return rows
 
-        if not overlap:
+        if share:
+            self.model.engine.dw_stream = None
+            main_loss = main_backward()
+            loss = main_loss.clone()
+            weights, stats = meta_update(loss)
+        elif not overlap:
             self.model.engine.dw_stream = None
             loss = no_grad_rows()
             weights, stats = meta_update(loss)

@@ -388,6 +388,37 @@ def test_side_stream_forwards_give_the_same_steps(neg_len):
         assert abs(a[3] - b[3]) < 1e-5
 
 
+def test_share_forward_gives_the_steps_of_the_two_pass_schedule():
+    """hparam share_forward (dropout 0 only): one forward serves the no-grad pass and the pass that keeps state."""
+    from pacednegatives_amd.lceT5 import LCEModel
+    from pacednegatives_amd.synthetic import token_batch
+    runs = []
+    for share in (False, True):
+        hp = {"model_name": "t5-tiny", "total_steps": 10, "eta": 30.0, "batch_size": 4, "lr": 1e-3, "meta_lr": 1e-2, "n": 3,
+              "warmup_steps": 0, "use_mean": False, "ignore_index": -100, "dropout": 0.0, "share_forward": share, "overlap_forwards": False}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = LCEModel(hp)
+        model.model.params.load_hf(init_params(RTINY, 0))
+        steps = []
+        for it in range(3):
+            out = model.training_step(token_batch(4, 3, 40, TINY.vocab_size, seed=300 + it), it)
+            steps.append((out["loss_rows"].cpu(), out["main_loss_rows"].cpu(), out["weights"].cpu(), model.difficulty))
+        runs.append(steps)
+    for it, (a, b) in enumerate(zip(*runs)):
+        if it == 0:
+            assert all(torch.equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3]
+        for x, y in zip(a[:3], b[:3]):            # later steps: weight gradients are summed with atomics
+            np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-3, atol=1e-6)
+        assert abs(a[3] - b[3]) < 1e-5
+    hp["dropout"] = 0.1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = LCEModel(hp)
+    with pytest.raises(ValueError, match="share_forward needs dropout 0"):
+        model.training_step(token_batch(4, 3, 40, TINY.vocab_size, seed=1), 0)
+
+
 def test_save_pretrained_round_trip(tmp_path):
     from pacednegatives_amd.model import T5ForConditionalGenerationHIP
     m, P = make_model(3)
