@@ -300,7 +300,7 @@ def main():
     ap.add_argument("--seq", type=int, default=256)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=3)
     ap.add_argument("--skip-mining", action="store_true")
     ap.add_argument("--mine_pool", type=int, default=10_000_000)
     ap.add_argument("--mine_queries", type=int, default=4096)

@@ -87,8 +87,10 @@ class LCEDataModule:
         if self.shuffle:
             import random
             random.shuffle(records)
+        # what pd.read_json(orient='records', dtype={'query_id': str, 'doc_id_a': str, ...}) gives the reference
+        # (lceT5.py:57-62): query and positive ids as strings, the negatives' ids as the JSON holds them
         self.pairs = [[str(r["query_id"]), str(r["doc_id_a"])] for r in records]
-        self.neg_idx = [[str(x) for x in r["doc_id_b"]] for r in records]
+        self.neg_idx = [list(r["doc_id_b"]) for r in records]
         self.dataset = LCEDataset(self.pairs, self.neg_idx, self.corpus, self.tokenizer, self.weight, self.batch_size,
                                   var=self.var, n=self.n, min=0. + 1e-10, max=1.0 - 1e-10, use_max=self.use_max)
         if self.propagate_pace:

@@ -241,3 +241,33 @@ def test_reference_import_line_resolves_to_this_package():
         assert hasattr(wt, name), name
     for name in ("PacedWrapper", "StdWrapper", "NewWrapper", "adjust_lr"):
         assert hasattr(pw, name), name
+
+
+def test_setup_reads_records_as_the_reference_does_with_pandas(tmp_path):
+    """LCEDataModule.setup reads the records with json; the reference reads them with
+    pd.read_json(f, orient='records', dtype={'query_id': str, 'doc_id_a': str, 'doc_id_b': List[str]}) (lceT5.py:57-62).
+    Same pairs and negative lists for ids with leading zeros, numeric strings, JSON integers and plain strings."""
+    import json
+    from typing import List
+    pd = pytest.importorskip("pandas")
+    from pacednegatives_amd.lceT5 import LCEDataModule
+    from pacednegatives_amd.synthetic import ListCorpus
+    recs = [{"query_id": "007", "doc_id_a": "0012", "doc_id_b": ["003", "14", "0005"]},
+            {"query_id": "1048585", "doc_id_a": "7187158", "doc_id_b": ["7187157", "99", "100"]},
+            {"query_id": 12, "doc_id_a": 34, "doc_id_b": [5, 6, 7]},
+            {"query_id": "q9", "doc_id_a": "d1", "doc_id_b": ["d2", "d3", "d4"]}]
+    path = tmp_path / "recs.json"
+    path.write_text(json.dumps(recs))
+    with open(path) as f:
+        ref = pd.read_json(f, orient="records", dtype={"query_id": str, "doc_id_a": str, "doc_id_b": List[str]})
+    want_pairs = ref[["query_id", "doc_id_a"]].values.tolist()
+    want_negs = [list(x) for x in ref["doc_id_b"].values]
+    ids = {x for r in recs for x in r["doc_id_b"]} | {str(r["doc_id_a"]) for r in recs}
+    corpus = ListCorpus([{"doc_id": i, "text": f"doc {i}"} for i in ids],
+                        [{"query_id": str(r["query_id"]), "text": f"query {r['query_id']}"} for r in recs])
+    dm = LCEDataModule(str(path), corpus, tokenizer=None, batch_size=2, n=2)
+    dm.setup()
+    assert dm.pairs == want_pairs
+    assert dm.neg_idx == want_negs and [type(x[0]) for x in dm.neg_idx] == [type(x[0]) for x in want_negs]
+    item = dm.dataset[2]            # the record with integer ids resolves against a corpus keyed the same way
+    assert item["pos"] == "Query: query 12 Document: doc 34 Relevant:" and len(item["neg"]) == 2
