@@ -46,7 +46,7 @@ def t5_forward_flops(dims, S, T=2):
 
 
 def run_train(args, rank, world, device):
-    from pacednegatives_amd import kernels as K
+    from pacednegatives_amd import kernels as K, parallel
     from pacednegatives_amd.config import resolve
     from pacednegatives_amd.lceT5 import LCEModel
     from pacednegatives_amd.synthetic import token_batch
@@ -74,10 +74,7 @@ def run_train(args, rank, world, device):
         model.training_step(batch, args.warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(elapsed, device)
 
     # one instrumented step: per-launch HIP events around the contraction kernel
     roof = None
@@ -191,7 +188,7 @@ def cpu_baseline_mining(pool_rows, queries, k, budget_s=20.0):
 
 def run_mining(args, rank, world, device):
     """Secondary figure: pool rows are sharded over ranks, queries replicated, shard results merged."""
-    from pacednegatives_amd import kernels as K, mining
+    from pacednegatives_amd import kernels as K, mining, parallel
     import torch.distributed as dist
     Q, D, k = args.mine_queries, 768, args.mine_k
     Np = args.mine_pool // world
@@ -217,11 +214,7 @@ def run_mining(args, rank, world, device):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / args.mine_iters
-    if world > 1:
-        t = torch.tensor([el], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = parallel.max_over_ranks((time.perf_counter() - t0) / args.mine_iters, device)
     total_rows = Np * world
     flops = 2.0 * Q * total_rows * D
     bytes_alg = total_rows * D * 2 + Q * D * 2 + Q * k * 12
@@ -308,6 +301,9 @@ def main():
     ap.add_argument("--mine_iters", type=int, default=2)
     args = ap.parse_args()
 
+    if os.environ.get("PACED_HANG_DUMP"):        # debugging aid: dump every thread's stack and exit after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PACED_HANG_DUMP"]), exit=True)
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))         # this process never touches the GPU
     from pacednegatives_amd.trainer import init_distributed

@@ -26,12 +26,33 @@ def rank() -> int:
     return d.get_rank() if d else 0
 
 
+def _host_staged(d) -> bool:
+    """gloo (CPU tests, rehearsals with several ranks on one GPU) is given host tensors only: its paths for device
+    tensors are little used upstream, and one such call hung here.  RCCL works on device memory directly."""
+    return d.get_backend() != "nccl"
+
+
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks (no-op for a single process)."""
     d = _dist()
     if d and d.get_world_size() > 1:
-        d.all_reduce(t, op=d.ReduceOp.SUM)
+        if t.is_cuda and _host_staged(d):
+            host = t.detach().cpu()              # also orders the exchange after the kernels that produced t
+            d.all_reduce(host, op=d.ReduceOp.SUM)
+            t.copy_(host)
+        else:
+            d.all_reduce(t, op=d.ReduceOp.SUM)
     return t
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """Largest ``value`` of any rank (the step time a multi-rank benchmark reports)."""
+    d = _dist()
+    if not d or d.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if _host_staged(d) or device is None else device)
+    d.all_reduce(t, op=d.ReduceOp.MAX)
+    return float(t.item())
 
 
 def all_gather_stack(t: torch.Tensor) -> torch.Tensor:
@@ -45,7 +66,7 @@ def all_gather_stack(t: torch.Tensor) -> torch.Tensor:
         return t.unsqueeze(0)
     W = d.get_world_size()
     t = t.contiguous()
-    if d.get_backend() == "nccl":
+    if not _host_staged(d):
         out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         d.all_gather_into_tensor(out, t)
         return out
