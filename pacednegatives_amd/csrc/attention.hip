@@ -14,6 +14,7 @@
 // ((n*H + h)*Tq + q)*Tk4 + key, Tk4 = Tk rounded up to a multiple of 4 (so that the 4 keys a lane holds
 // in consecutive registers always share one hash evaluation), identical in forward and backward.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -149,7 +150,11 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
 
     const int ntile = (S + 63) / 64;
     Tile64 kreg = load_tile64(K + rowbase * a.ld, a.ld, 0, S), vreg = load_tile64(V + rowbase * a.ld, a.ld, 0, S);
-    for (int kt = 0; kt < ntile; ++kt) {
+    // One 64-key tile.  RAGGED (a compile-time tag) is the tile that holds the end of the sequence when S is not a
+    // multiple of 64: only that copy of the body carries the per-key masks (as a run-time test inside one body the
+    // compiler turns them into a compare and a select per score on every tile).
+    auto tile = [&](int kt, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         __syncthreads();
         store_tile64(kreg, lK, nullptr);
         store_tile64(vreg, nullptr, lV);
@@ -171,7 +176,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lK, 32 * j, ks, lane), qf[ks], s[j], 0, 0, 0);
-            if (kt * 64 + 64 > S) {          // only the last, ragged tile has keys to mask
+            if (RAGGED) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kt * 64 + 32 * j + acc_row(r, hh) >= S) s[j][r] = -INFINITY;
@@ -213,7 +218,10 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lV, 32 * j + 16 * s2, 0, lane), pf, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lV, 32 * j + 16 * s2, 1, lane), pf, o1, 0, 0, 0);
             }
-    }
+    };
+    const int nfull = S / 64;
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < ntile) tile(nfull, std::true_type{});
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = (DROP ? a.drop.scale : 1.f) / l_tot;
     if (q < S) {
