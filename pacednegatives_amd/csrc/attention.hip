@@ -110,11 +110,12 @@ __device__ __forceinline__ void store_tile64(const Tile64& t, char* row_img, cha
     }
 }
 
+// registers 8*s2 .. 8*s2+7 of an accumulator tile as one bf16 fragment.  Converted as one vector (pairs of values per
+// v_cvt_pk_bf16_f32); element by element the compiler converts each value alone and merges the halves with v_perm_b32.
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(a[8 * s2 + e]);
-    return o;
+    const f32x8 lo = __builtin_shufflevector(a, a, 0, 1, 2, 3, 4, 5, 6, 7);
+    const f32x8 hi = __builtin_shufflevector(a, a, 8, 9, 10, 11, 12, 13, 14, 15);
+    return __builtin_convertvector(s2 ? hi : lo, bf16x8);
 }
 
 }  // namespace
