@@ -52,8 +52,14 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // value of lane (l & ~3) + E for every lane l (DPP quad_perm broadcast)
 template <int E>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, E * 0x55, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, E * 0x55, 0xf, 0xf, true);      // every lane has a source: no old value to keep
 }
+
+// DPP exchanges inside groups of 8 lanes (no LDS round trip): lane ^ 1, lane ^ 2, and lane 7 - i of the group (which,
+// once the four lanes of each quad hold the same value, brings in the other quad's)
+__device__ __forceinline__ float lane_xor1(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xf, 0xf, true)); }
+__device__ __forceinline__ float lane_xor2(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xf, 0xf, true)); }
+__device__ __forceinline__ float lane_mirror8(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xf, 0xf, true)); }
 
 __device__ __forceinline__ bf16x8 load8(const bf16* p, bool ok) {
     bf16x8 z;
@@ -61,6 +67,52 @@ __device__ __forceinline__ bf16x8 load8(const bf16* p, bool ok) {
     for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
     return ok ? *reinterpret_cast<const bf16x8*>(p) : z;
 }
+
+// Buffer descriptor over `rows` rows (stride ld elements) of a row-major bf16 matrix, `width` elements of each row
+// starting at `base`: a load whose byte offset lies past the last row returns zeros, so ragged tiles need neither a
+// branch nor a select, and offsets are 32-bit (no 64-bit address arithmetic per load).  `base` is uniform.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const bf16* base, int ld, int rows, int width) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((size_t)(rows - 1) * ld + width) * 2), 0x00020000);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t floats_rsrc(const float* base, int count) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, base ? count * 4 : 0, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 bload8(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ float bloadf(__amdgpu_buffer_rsrc_t r, int index) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, index * 4, 0, 0));
+}
+
+// The per-head bias table (2S-1 entries, index key - query + S - 1) staged in LDS with `front` zeros before it and
+// zeros up to `total` entries.  The loads of a round of four entries per thread are issued together: one memory round
+// trip per 1024 entries (a load/wait/store loop pays one per 256).
+__device__ __forceinline__ void stage_bias(__amdgpu_buffer_rsrc_t rb, float* lbias, int front, int total) {
+    for (int i0 = threadIdx.x; i0 < total; i0 += 1024) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u - front;
+            v[u] = bloadf(rb, i < 0 ? 0x1fffffff : i);          // outside the table: an offset past the descriptor's range reads 0
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256 * u < total) lbias[i0 + 256 * u] = v[u];
+    }
+}
+
+#ifdef DBG_STAMPS
+#define STAMP_DECL __shared__ long long stamps[16];
+#define STAMP(k) do { if (threadIdx.x == 0) stamps[k] = (k) == 0 || (k) == 14 ? wall_clock64() : clock64(); } while (0)
+#define STAMP_DUMP(ptr) do { __syncthreads(); if ((ptr) && threadIdx.x < 15) { \
+        const size_t bid = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z); \
+        reinterpret_cast<long long*>(ptr)[bid * 15 + threadIdx.x] = stamps[threadIdx.x]; } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_DUMP(ptr)
+#endif
 
 struct AttnArgs {
     const bf16* q; const bf16* k; const bf16* v;   // row (n*S + s), head h at column h*64; row stride ld
@@ -92,12 +144,13 @@ __device__ __forceinline__ void stage_tile(const bf16* src, int ld, int first_ro
 // Loading (global -> registers) and storing (registers -> LDS images) are separate so that the loads of
 // the NEXT tile can be issued before the current tile is consumed.
 struct Tile64 { bf16x8 v[2]; };
-__device__ __forceinline__ Tile64 load_tile64(const bf16* src, int ld, int first_row, int valid_rows) {
+// rows first_row .. first_row + 63 of the matrix behind `r` (row stride ld elements); rows past its range come back as zeros
+__device__ __forceinline__ Tile64 load_tile64(__amdgpu_buffer_rsrc_t r, int ld, int first_row) {
     Tile64 t;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int g = threadIdx.x + i * 256, r = g >> 3, c = g & 7;
-        t.v[i] = load8(src + (size_t)(first_row + r) * ld + c * 8, first_row + r < valid_rows);
+        const int g = threadIdx.x + i * 256, row = g >> 3, c = g & 7;
+        t.v[i] = bload8(r, ((first_row + row) * ld + c * 8) * 2);
     }
     return t;
 }
@@ -135,14 +188,15 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     const int q = blockIdx.x * 128 + w * 32 + (lane & 31);
     const int qc = min(q, S - 1);
     const size_t rowbase = (size_t)n * S;
-    const bf16* Q = a.q + h * DK; const bf16* K = a.k + h * DK; const bf16* V = a.v + h * DK;
-
-    for (int i = threadIdx.x; i < 2 * S + 64; i += 256)
-        lbias[i] = (a.bias && i < 2 * S - 1) ? a.bias[(size_t)h * (2 * S - 1) + i] : 0.f;
-
+    // every global load of the prologue is issued before the first wait: one memory round trip, not one per operand
+    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * DK, a.ld, S, DK);
     bf16x8 qf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = load8(Q + (rowbase + qc) * a.ld + 16 * ks + 8 * hh, q < S);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = bload8(rQ, (qc * a.ld + 16 * ks + 8 * hh) * 2);
+    Tile64 kreg = load_tile64(rK, a.ld, 0), vreg = load_tile64(rV, a.ld, 0);
+    stage_bias(floats_rsrc(a.bias ? a.bias + (size_t)h * (2 * S - 1) : nullptr, 2 * S - 1), lbias, 0, 2 * S + 64);
 
     f32x16 o0, o1;
 #pragma unroll
@@ -150,7 +204,6 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntile = (S + 63) / 64;
-    Tile64 kreg = load_tile64(K + rowbase * a.ld, a.ld, 0, S), vreg = load_tile64(V + rowbase * a.ld, a.ld, 0, S);
     // One 64-key tile.  RAGGED (a compile-time tag) is the tile that holds the end of the sequence when S is not a
     // multiple of 64: only that copy of the body carries the per-key masks (as a run-time test inside one body the
     // compiler turns them into a compare and a select per score on every tile).
@@ -161,8 +214,8 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
         store_tile64(vreg, nullptr, lV);
         __syncthreads();
         if (kt + 1 < ntile) {     // the next tile's loads fly under this tile's arithmetic
-            kreg = load_tile64(K + rowbase * a.ld, a.ld, (kt + 1) * 64, S);
-            vreg = load_tile64(V + rowbase * a.ld, a.ld, (kt + 1) * 64, S);
+            kreg = load_tile64(rK, a.ld, (kt + 1) * 64);
+            vreg = load_tile64(rV, a.ld, (kt + 1) * 64);
         }
 
         f32x16 s[2];
@@ -240,51 +293,85 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
 }
 
 // ====================================================================== backward: dK, dV, dBias
+// One step of the bias gradient's diagonal sums: row R of the 32x32 dS tile (query 8*(R>>2) + (R&3) + 4*half at this
+// lane's key) rotated left by A = 8*(R>>2) + (R&3) lanes inside each 32-lane half (ds_swizzle rotate mode: an
+// immediate, no address register).  Lane j of the lower half then holds the element of diagonal j (key - query,
+// relative to the tile), of the upper half that of diagonal j - 4; elements that wrapped around (j + A >= 32) belong
+// to diagonal j - 32 (- 4) and are summed apart.
+template <int R>
+__device__ __forceinline__ void diag_step(const f32x16& ds, int j, float& all, float& wrapped) {
+    constexpr int A = (R & 3) + 8 * (R >> 2);
+    const float x = ds[R];       // (a bit cast applied to the vector element itself reads element 0)
+    const float v = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0xC000 | (A << 5)));
+    all += v;
+    wrapped += (j >= 32 - A) ? v : 0.f;
+}
+
 // grid (ceil(S/128), H, N): wave w owns keys kb + 32w .. +32 and sweeps all queries in tiles of 32.
 template <bool DROP>
 __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PAD = 32;        // table entries in front of index 0: query rows past S (last tile) index below it
     char* lQr = smem;              // 32 x 64 row image of Q
     char* lQt = smem + 4096;       // tr image of Q
     char* lDr = smem + 8192;       // row image of dO
     char* lDt = smem + 12288;      // tr image of dO
     float* llse = reinterpret_cast<float*>(smem + 16384);     // 32
     float* ldel = llse + 32;                                  // 32
-    float* lbias = ldel + 32;                                 // 2S + 160
-    float* ldb = lbias + (2 * a.S + 160);                     // 2S + 160
+    float* lbias = ldel + 32;                                 // PAD + 2S + 160
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5;
     const int n = blockIdx.z, h = blockIdx.y, S = a.S;
+    const int LB = 2 * S + 160;
+    float* ldb = lbias + PAD + LB;                            // 2S + 160
     const int key = blockIdx.x * 128 + w * 32 + (lane & 31);
     const int keyc = min(key, S - 1);
     const size_t rowbase = (size_t)n * S;
-    const bf16* Q = a.q + h * DK; const bf16* K = a.k + h * DK; const bf16* V = a.v + h * DK;
-    const bf16* O = a.o + h * DK; const bf16* DO = a.dout + h * DK;
-    const int LB = 2 * S + 160;
-
-    for (int i = threadIdx.x; i < LB; i += 256) {
-        lbias[i] = (a.bias && i < 2 * S - 1) ? a.bias[(size_t)h * (2 * S - 1) + i] : 0.f;
-        ldb[i] = 0.f;
-    }
+    STAMP_DECL
+    STAMP(0); STAMP(1);
+    // every global load of the prologue is issued before the first wait; rows past S read as zeros
+    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rO = rows_rsrc(a.o + rowbase * a.ldo + h * DK, a.ldo, S, DK);
+    const __amdgpu_buffer_rsrc_t rD = rows_rsrc(a.dout + rowbase * a.lddo + h * DK, a.lddo, S, DK);
+    const __amdgpu_buffer_rsrc_t rL = floats_rsrc(a.lse + ((size_t)n * a.H + h) * S, S);
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = load8(K + (rowbase + keyc) * a.ld + 16 * ks + 8 * hh, key < S);
-        vf[ks] = load8(V + (rowbase + keyc) * a.ld + 16 * ks + 8 * hh, key < S);
+        kf[ks] = bload8(rK, (key * a.ld + 16 * ks + 8 * hh) * 2);
+        vf[ks] = bload8(rV, (key * a.ld + 16 * ks + 8 * hh) * 2);
     }
-    f32x16 dk0, dk1, dv0, dv1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
-
-    float carry = 0.f;
-    const int ntile = (S + 31) / 32;
     // staged per query tile: one 16-byte chunk of Q, dO and O per thread (row = thread >> 3) and the row's LSE;
     // the next tile's loads are issued before the current tile is consumed
     const int sr = threadIdx.x >> 3, sc = threadIdx.x & 7;
-    bf16x8 qv = load8(Q + (rowbase + sr) * a.ld + sc * 8, sr < S);
-    bf16x8 dv = load8(DO + (rowbase + sr) * a.lddo + sc * 8, sr < S);
-    bf16x8 ov = load8(O + (rowbase + sr) * a.ldo + sc * 8, sr < S);
-    float lsev = (sr < S) ? a.lse[((size_t)n * a.H + h) * S + sr] : 0.f;
-    for (int qt = 0; qt < ntile; ++qt) {
+    bf16x8 qv = bload8(rQ, (sr * a.ld + sc * 8) * 2);
+    bf16x8 dv = bload8(rD, (sr * a.lddo + sc * 8) * 2);
+    bf16x8 ov = bload8(rO, (sr * a.ldo + sc * 8) * 2);
+    float lsev = bloadf(rL, sr);
+    stage_bias(floats_rsrc(a.bias ? a.bias + (size_t)h * (2 * S - 1) : nullptr, 2 * S - 1), lbias, PAD, PAD + LB);
+    for (int i = threadIdx.x; i < LB; i += 256) ldb[i] = 0.f;
+    f32x16 dk0, dk1, dv0, dv1, zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; zero16[r] = 0.f; }
+
+    // A key past S gives probability 0 through the exponent (its dS must not reach the bias gradient; its dK/dV rows
+    // are not stored).  Query rows past S need no mask: their Q, dO, delta and LSE are staged as zeros, so dS = 0 and
+    // p * dO = 0.
+    const float kneg = key < S ? 0.f : -1e30f;
+    // dropout: the 16-bit field of this lane's key inside the two hash words of an aligned key quad, as a v_perm_b32 selector
+    const uint32_t fsel = 0x0c0c0000u | ((2u * (keyc & 3) + 1u) << 8) | (2u * (keyc & 3));
+    const uint64_t S4q = (uint64_t)((S + 3) & ~3) >> 2;
+    // hash quad number of (query 4*hh + (lane & 3), this lane's key quad); + 8 * S4q per register group, + 32 * S4q per tile
+    uint64_t hq = (((uint64_t)n * a.H + h) * S + 4 * hh + (lane & 3)) * S4q + (keyc >> 2);
+
+    float carry = 0.f;
+    const int ntile = (S + 31) / 32;
+    // bias entry of (this lane's key, query 4*hh of the tile): register r reads lb[-(8*(r>>2) + (r&3))]
+    const float* lb = lbias + (PAD + keyc + S - 1 - 4 * hh);
+    const float* lse4 = llse + 4 * hh;
+    const float* del4 = ldel + 4 * hh;
+    for (int qt = 0; qt < ntile; ++qt, lb -= 32, hq += 32 * S4q) {
+        if (qt == 0) STAMP(2);
         __syncthreads();
         {   // stage Q and dO tiles and delta = rowsum(dO * O)
             *reinterpret_cast<bf16x8*>(lQr + row_img_off(sr, sc)) = qv;
@@ -294,38 +381,36 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             float d = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) d += bf2f(dv[j]) * bf2f(ov[j]);
-            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            d += lane_xor1(d); d += lane_xor2(d); d += lane_mirror8(d);       // sum over the row's 8 threads
             if (sc == 0) {
                 ldel[sr] = d;
                 llse[sr] = lsev;
             }
         }
         __syncthreads();
+        if (qt < 4) STAMP(3 + 2 * qt);
         if (qt + 1 < ntile) {
             const int qrow = (qt + 1) * 32 + sr;
-            const bool ok = qrow < S;
-            qv = load8(Q + (rowbase + qrow) * a.ld + sc * 8, ok);
-            dv = load8(DO + (rowbase + qrow) * a.lddo + sc * 8, ok);
-            ov = load8(O + (rowbase + qrow) * a.ldo + sc * 8, ok);
-            lsev = ok ? a.lse[((size_t)n * a.H + h) * S + qrow] : 0.f;
+            qv = bload8(rQ, (qrow * a.ld + sc * 8) * 2);
+            dv = bload8(rD, (qrow * a.lddo + sc * 8) * 2);
+            ov = bload8(rO, (qrow * a.ldo + sc * 8) * 2);
+            lsev = bloadf(rL, qrow);
         }
 
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ql = acc_row(r, hh);
-            const int qq = min(qt * 32 + ql, S - 1);
-            s[r] = lbias[keyc - qq + S - 1] - llse[ql];
-            dp[r] = 0.f;
+            const int o = (r & 3) + 8 * (r >> 2);
+            s[r] = lb[-o] - lse4[o];
         }
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lQr, 0, 0, lane), kf[0], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lDr, 0, 0, lane), vf[0], zero16, 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 1; ks < 4; ++ks) {
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lQr, 0, ks, lane), kf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lDr, 0, ks, lane), vf[ks], dp, 0, 0, 0);
         }
         f32x16 pd;   // dropped probabilities (feeds dV); s becomes dS (feeds dK)
-        const uint64_t dnh = ((uint64_t)n * a.H + h) * S;
-        const uint64_t S4 = (uint64_t)((S + 3) & ~3);
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             // Registers 4rg..4rg+3 hold 4 consecutive queries at this lane's key; the hash covers 4
@@ -333,49 +418,39 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             // 4 hashes: lane (l & 3) evaluates the one of query q4 + (l & 3) and a quad broadcast hands
             // each to the other three.
             uint32_t w0 = 0, w1 = 0;
-            const int q4 = qt * 32 + acc_row(4 * rg, hh);
-            if (DROP)
-                paced_drop_words(a.drop.seed, ((dnh + min(q4 + (lane & 3), S - 1)) * S4 + (keyc & ~3)) >> 2, w0, w1);
+            if (DROP) paced_drop_words(a.drop.seed, hq + (uint64_t)(8 * rg) * S4q, w0, w1);
             uint32_t b0[4], b1[4];                     // words of queries q4 .. q4+3 (quad broadcasts of lanes 0..3)
             b0[0] = quad_bcast<0>(w0); b0[1] = quad_bcast<1>(w0); b0[2] = quad_bcast<2>(w0); b0[3] = quad_bcast<3>(w0);
             b1[0] = quad_bcast<0>(w1); b1[1] = quad_bcast<1>(w1); b1[2] = quad_bcast<2>(w1); b1[3] = quad_bcast<3>(w1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * rg + e;
-                const int ql = acc_row(r, hh);
-                const int qq = qt * 32 + ql;
-                const bool ok = (qq < S) && (key < S);
-                const float p = ok ? __expf(s[r]) : 0.f;
+                const int o = e + 8 * rg;
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, kneg));
                 float f = 1.f;
-                if (DROP) {
-                    const uint32_t wsel = (keyc & 2) ? b1[e] : b0[e];
-                    const uint32_t field = (keyc & 1) ? (wsel >> 16) : (wsel & 0xffffu);
-                    f = field >= a.drop.thresh ? a.drop.scale : 0.f;
-                }
+                if (DROP) f = __builtin_amdgcn_perm(b1[e], b0[e], fsel) >= a.drop.thresh ? a.drop.scale : 0.f;
                 pd[r] = p * f;
-                s[r] = p * (dp[r] * f - ldel[ql]);
+                s[r] = p * (dp[r] * f - del4[o]);
             }
         }
         if (a.dbias) {
-            // Bias gradient = sums of dS along diagonals (key - query = const).  Rotate row ql of the
-            // 32x32 tile left by ql lanes (ds_bpermute): lane j then holds the element of diagonal
-            // j (no wrap) or j-32 (wrapped); two running sums per lane cover the tile's 63 diagonals.
-            // The wrapped half of this tile and the unwrapped half of the next query tile are the same
-            // diagonals, so it is carried in a register and each diagonal costs ONE LDS atomic in all.
-            float Ps = 0.f, Ns = 0.f;
+            // Bias gradient = sums of dS along diagonals (key - query = const); two running sums per lane cover the
+            // tile's diagonals.  The wrapped part of this tile and the unwrapped part of the next query tile are the
+            // same diagonals, so it is carried in a register and each diagonal costs ONE LDS atomic per half wave.
             const int j = lane & 31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = acc_row(r, hh);
-                const float v = __shfl(s[r], (hh << 5) | ((j + ql) & 31), 64);
-                if (j + ql < 32) Ps += v; else Ns += v;
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the live range: 4 permutes in flight
-            }
-            Ps += __shfl_xor(Ps, 32, 64);
-            Ns += __shfl_xor(Ns, 32, 64);
-            const int idx = (blockIdx.x * 128 + w * 32 + j) - qt * 32 + S - 1;      // diagonal base + j
-            if (hh == 0 && idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], Ps + carry);
-            carry = Ns;
+            float all = s[0], wrapped = 0.f;
+            diag_step<1>(s, j, all, wrapped);   diag_step<2>(s, j, all, wrapped);   diag_step<3>(s, j, all, wrapped);
+            diag_step<4>(s, j, all, wrapped);   diag_step<5>(s, j, all, wrapped);   diag_step<6>(s, j, all, wrapped);
+            diag_step<7>(s, j, all, wrapped);   diag_step<8>(s, j, all, wrapped);   diag_step<9>(s, j, all, wrapped);
+            diag_step<10>(s, j, all, wrapped);  diag_step<11>(s, j, all, wrapped);  diag_step<12>(s, j, all, wrapped);
+            diag_step<13>(s, j, all, wrapped);  diag_step<14>(s, j, all, wrapped);  diag_step<15>(s, j, all, wrapped);
+            const int idx = (blockIdx.x * 128 + w * 32 + j) - qt * 32 + S - 1 - 4 * hh;      // diagonal of lane j
+#ifndef DBG_NO_LATOMIC
+            if (idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], (all - wrapped) + carry);
+            carry = wrapped;
+#else
+            carry += all - wrapped;
+#endif
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -385,7 +460,9 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lQt, 16 * s2, 0, lane), df, dk0, 0, 0, 0);
             dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lQt, 16 * s2, 1, lane), df, dk1, 0, 0, 0);
         }
+        if (qt < 4) STAMP(4 + 2 * qt);
     }
+    STAMP(11);
     if (key < S) {
         bf16* dkrow = a.dk + (rowbase + key) * a.ldd + h * DK;
         bf16* dvrow = a.dv + (rowbase + key) * a.ldd + h * DK;
@@ -403,17 +480,30 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * rg + 4 * hh) = v1;
         }
     }
+    STAMP(12);
     if (a.dbias) {
-        const int idx = (blockIdx.x * 128 + w * 32 + (lane & 31)) - (ntile - 1) * 32 - 32 + S - 1;   // wrapped half of the last tile
-        if (hh == 0 && idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], carry);
+        const int idx = (blockIdx.x * 128 + w * 32 + (lane & 31)) - ntile * 32 + S - 1 - 4 * hh;   // wrapped part of the last tile
+        if (idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], carry);
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * S - 1; i += 256) {
             const float v = ldb[i];
             // every workgroup of a head adds to the same 2S-1 words; replicas keep same-address atomics apart
             const int rep = (blockIdx.z * gridDim.x + blockIdx.x) % a.dbias_replicas;
+#ifndef DBG_NO_GATOMIC
             if (v != 0.f) atomicAdd(a.dbias + ((size_t)rep * a.H + h) * (2 * S - 1) + i, v);
+#else
+            if (v == 123.f) a.dbias[i] = v;
+#endif
         }
     }
+    STAMP(13); STAMP(14);
+#ifdef DBG_STAMPS_DKDV
+    __syncthreads();
+    if (threadIdx.x < 15) {
+        const size_t bid = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        reinterpret_cast<long long*>(a.dq + bid * a.ldd)[threadIdx.x] = stamps[threadIdx.x];
+    }
+#endif
 }
 
 // ================================================================================ backward: dQ
@@ -430,65 +520,85 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
     const int q = blockIdx.x * 128 + w * 32 + (lane & 31);
     const int qc = min(q, S - 1);
     const size_t rowbase = (size_t)n * S;
-    const bf16* Q = a.q + h * DK; const bf16* K = a.k + h * DK; const bf16* V = a.v + h * DK;
-    const bf16* O = a.o + h * DK; const bf16* DO = a.dout + h * DK;
+#ifdef DBG_STAMPS_DKDV
+    if (a.S > 0) return;          // the other kernel's stamps live in this kernel's output
+#endif
+    STAMP_DECL
+    STAMP(0); STAMP(1);
 
-    for (int i = threadIdx.x; i < 2 * S + 64; i += 256)
-        lbias[i] = (a.bias && i < 2 * S - 1) ? a.bias[(size_t)h * (2 * S - 1) + i] : 0.f;
-
-    bf16x8 qf[4], dof[4];
-    float delta = 0.f;
+    // every global load of the prologue is issued before the first wait; rows past S read as zeros
+    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rO = rows_rsrc(a.o + rowbase * a.ldo + h * DK, a.ldo, S, DK);
+    const __amdgpu_buffer_rsrc_t rD = rows_rsrc(a.dout + rowbase * a.lddo + h * DK, a.lddo, S, DK);
+    bf16x8 qf[4], dof[4], of[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = load8(Q + (rowbase + qc) * a.ld + 16 * ks + 8 * hh, q < S);
-        dof[ks] = load8(DO + (rowbase + qc) * a.lddo + 16 * ks + 8 * hh, q < S);
-        const bf16x8 ov = load8(O + (rowbase + qc) * a.ldo + 16 * ks + 8 * hh, q < S);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) delta += bf2f(dof[ks][j]) * bf2f(ov[j]);
+        qf[ks] = bload8(rQ, (qc * a.ld + 16 * ks + 8 * hh) * 2);
+        dof[ks] = bload8(rD, (qc * a.lddo + 16 * ks + 8 * hh) * 2);
+        of[ks] = bload8(rO, (qc * a.ldo + 16 * ks + 8 * hh) * 2);
     }
-    delta += __shfl_xor(delta, 32, 64);
-    const float lse = a.lse[((size_t)n * a.H + h) * S + qc];
-
-    f32x16 dq0, dq1;
+    const float lse = bloadf(floats_rsrc(a.lse + ((size_t)n * a.H + h) * S, S), qc);
+    Tile64 kreg = load_tile64(rK, a.ld, 0), vreg = load_tile64(rV, a.ld, 0);
+    stage_bias(floats_rsrc(a.bias ? a.bias + (size_t)h * (2 * S - 1) : nullptr, 2 * S - 1), lbias, 0, 2 * S + 64);
+    float delta = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf2f(dof[ks][j]) * bf2f(of[ks][j]);
+    delta += __shfl_xor(delta, 32, 64);
+
+    f32x16 dq0, dq1, zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; zero16[r] = 0.f; }
+
+    // No mask on keys past S (last tile): their K and V rows are staged as zeros, so dP = 0, the scores are finite
+    // (bias table padded with zeros) and dS * K adds nothing.
+    const float nl = -lse * LOG2E;                                    // p = exp2(s * log2(e) + nl), s = bias + q.k
+    const float* lbq = lbias + (S - 1 - qc + 4 * hh);                 // bias entry of (this lane's query, key 4*hh)
+    // hash quad number of (this lane's query, keys 4*hh ..): + 2 per register group, + 8 per 32 keys
+    const uint64_t hq = (((((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3)) >> 2) + hh;
 
     const int ntile = (S + 63) / 64;
-    Tile64 kreg = load_tile64(K + rowbase * a.ld, a.ld, 0, S), vreg = load_tile64(V + rowbase * a.ld, a.ld, 0, S);
     for (int kt = 0; kt < ntile; ++kt) {
+        if (kt < 4) STAMP(2 + 3 * kt);
         __syncthreads();
         store_tile64(kreg, lKr, lKt);
         store_tile64(vreg, lVr, nullptr);
         __syncthreads();
+        if (kt < 4) STAMP(3 + 3 * kt);
         if (kt + 1 < ntile) {
-            kreg = load_tile64(K + rowbase * a.ld, a.ld, (kt + 1) * 64, S);
-            vreg = load_tile64(V + rowbase * a.ld, a.ld, (kt + 1) * 64, S);
+            kreg = load_tile64(rK, a.ld, (kt + 1) * 64);
+            vreg = load_tile64(rV, a.ld, (kt + 1) * 64);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + 32 * j + acc_row(r, hh);
-                s[r] = lbias[key - qc + S - 1] - lse;
-                dp[r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) s[r] = lbq[kt * 64 + 32 * j + (r & 3) + 8 * (r >> 2)];
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lKr, 32 * j, 0, lane), qf[0], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lVr, 32 * j, 0, lane), dof[0], zero16, 0, 0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 1; ks < 4; ++ks) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lKr, 32 * j, ks, lane), qf[ks], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(lVr, 32 * j, ks, lane), dof[ks], dp, 0, 0, 0);
             }
-            const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3);
-            const bool full = kt * 64 + 64 <= S;          // no key of this tile is out of range (uniform)
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                const int key = kt * 64 + 32 * j + acc_row(r, hh);          // multiple of 4; registers r+1..r+3 hold key+1..key+3
-                float f[4] = {1.f, 1.f, 1.f, 1.f};
-                if (DROP) drop_factor4_on(a.drop, dbase + key, f);
+            for (int rg = 0; rg < 4; ++rg) {           // registers 4rg .. 4rg+3 hold 4 consecutive keys: one hash evaluation
+                uint32_t w0 = 0, w1 = 0;
+                if (DROP) paced_drop_words(a.drop.seed, hq + (uint64_t)(kt * 16 + 8 * j + 2 * rg), w0, w1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = (full || key + e < S) ? __expf(s[r + e]) : 0.f;
-                    s[r + e] = pe * (dp[r + e] * f[e] - delta);
+                    const int r = 4 * rg + e;
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, nl));
+                    float f = 1.f;
+                    if (DROP) {
+                        const uint32_t word = e < 2 ? w0 : w1;
+                        const uint32_t field = (e & 1) ? (word >> 16) : (word & 0xffffu);
+                        f = field >= a.drop.thresh ? a.drop.scale : 0.f;
+                    }
+                    s[r] = pe * (dp[r] * f - delta);
                 }
             }
 #pragma unroll
@@ -497,8 +607,13 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
                 dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lKt, 32 * j + 16 * s2, 0, lane), df, dq0, 0, 0, 0);
                 dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lKt, 32 * j + 16 * s2, 1, lane), df, dq1, 0, 0, 0);
             }
+            if (kt < 4 && j == 0) STAMP(4 + 3 * kt);
         }
     }
+    STAMP(14);
+#ifdef DBG_STAMPS_DQ
+    STAMP_DUMP(a.dbias);
+#endif
     if (q < S) {
         bf16* dqrow = a.dq + (rowbase + q) * a.ldd + h * DK;
 #pragma unroll
@@ -1069,7 +1184,7 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
     a.lse = const_cast<float*>(lse); a.bias = bias_tbl; a.dbias = dbias_tbl; a.dbias_replicas = dbias_replicas;
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const dim3 grid((S + 127) / 128, H, N);
-    const size_t smem1 = 16384 + (size_t)(64 + 2 * (2 * S + 160)) * 4;
+    const size_t smem1 = 16384 + (size_t)(64 + 32 + 2 * (2 * S + 160)) * 4;
     if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<true>), grid, dim3(256), smem1, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<false>), grid, dim3(256), smem1, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();

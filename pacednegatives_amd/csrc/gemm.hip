@@ -14,6 +14,7 @@
 // descriptor's range check (loads beyond num_records return zero), so ragged M/N and a ragged
 // token contraction need no host-side padding.  Two tile configurations: see below.
 #include "gemm.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -923,7 +924,11 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const int ntm = (p.M + Cfg::BM - 1) / Cfg::BM, ntn = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int ktiles = (p.K + BK - 1) / BK;
     constexpr bool PHASED = std::is_same<Cfg, CfgPhased>::value;
-    const int slots = cu_count() * (PHASED ? 1 : std::is_same<Cfg, CfgTiny>::value ? 6 : 3);     // workgroups resident per CU
+    int slots = cu_count() * (PHASED ? 1 : std::is_same<Cfg, CfgTiny>::value ? 6 : 3);     // workgroups resident per CU
+    if (PHASED) {        // PACED_GEMM_GRID=n: at most n workgroups (diagnostic: how the rate scales with the CUs in use)
+        static const int limit = [] { const char* e = getenv("PACED_GEMM_GRID"); return e ? atoi(e) : 0; }();
+        if (limit > 0 && limit < slots) slots = limit;
+    }
     constexpr bool RINGABLE = !PHASED && EPI != EPI_TOPK_DENSE && EPI != EPI_TOPK_FILTER;
     const bool ring_on = ring_enabled();
     if (splits <= 0) {          // auto: fill the grid once, keep >= 4 K steps per slice
