@@ -114,6 +114,23 @@ __device__ __forceinline__ void stage_bias(__amdgpu_buffer_rsrc_t rb, float* lbi
 #define STAMP_DUMP(ptr)
 #endif
 
+// Workgroup -> (block x of the sequence, head, sequence) for a grid of nx * H * N workgroups.  The hardware deals
+// workgroups to the 8 XCDs in launch order, so consecutive ids never share an L2.  The nx blocks of one (sequence, head)
+// read the same K and V: they are given ids 8 apart -- same XCD, started back to back -- so that the second one's
+// fetches hit the L2 lines the first one brought in.  (Used by the dQ kernel: 2 % there; the forward kernel with
+// dropout lost 9 % to the different register allocation the computed indices led to, the dK/dV kernel gained nothing.)
+struct BlockId { int x, h, n; };
+__device__ __forceinline__ BlockId block_of(int nx, int H, int N) {
+    const int L = blockIdx.x + nx * (blockIdx.y + H * blockIdx.z);
+    const int total = nx * H * N, span = 8 * nx;
+    int x, p;
+    const int main_part = total - total % span;
+    if (L < main_part) { const int g = L / span, r = L - g * span; x = r >> 3; p = 8 * g + (r & 7); }
+    else { const int r = L - main_part; p = main_part / nx + r / nx; x = r % nx; }      // the ragged end: launch order
+    BlockId b; b.x = x; b.h = p % H; b.n = p / H;
+    return b;
+}
+
 struct AttnArgs {
     const bf16* q; const bf16* k; const bf16* v;   // row (n*S + s), head h at column h*64; row stride ld
     int ld;
@@ -153,6 +170,27 @@ __device__ __forceinline__ Tile64 load_tile64(__amdgpu_buffer_rsrc_t r, int ld, 
         t.v[i] = bload8(r, ((first_row + row) * ld + c * 8) * 2);
     }
     return t;
+}
+// Rows first_row .. first_row + 127, four 16-byte pieces per thread (piece i: row (t + 256 i) >> 3, chunk t & 7): every
+// 128-byte line of the block is requested by exactly one wave instruction.  (Fetching MFMA fragments straight from
+// global memory -- lane = row, 16 bytes per lane -- touches 32 lines per instruction and each line from eight different
+// instructions; the L1 then stalls on hits to lines whose miss is still pending.)
+struct Tile128 { bf16x8 v[4]; };
+__device__ __forceinline__ Tile128 load_tile128(__amdgpu_buffer_rsrc_t r, int ld, int first_row) {
+    Tile128 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = threadIdx.x + i * 256, row = g >> 3, c = g & 7;
+        t.v[i] = bload8(r, ((first_row + row) * ld + c * 8) * 2);
+    }
+    return t;
+}
+__device__ __forceinline__ void store_tile128(const Tile128& t, char* row_img) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = threadIdx.x + i * 256, r = g >> 3, c = g & 7;
+        *reinterpret_cast<bf16x8*>(row_img + row_img_off(r, c)) = t.v[i];
+    }
 }
 __device__ __forceinline__ void store_tile64(const Tile64& t, char* row_img, char* tr_img) {
 #pragma unroll
@@ -260,6 +298,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
                     s[j][r + e] = keep[e] ? pe : 0.f;
                 }
             }
+
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
@@ -320,10 +359,10 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     float* ldel = llse + 32;                                  // 32
     float* lbias = ldel + 32;                                 // PAD + 2S + 160
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5;
-    const int n = blockIdx.z, h = blockIdx.y, S = a.S;
+    const int n = blockIdx.z, h = blockIdx.y, bx = blockIdx.x, S = a.S;
     const int LB = 2 * S + 160;
     float* ldb = lbias + PAD + LB;                            // 2S + 160
-    const int key = blockIdx.x * 128 + w * 32 + (lane & 31);
+    const int key = bx * 128 + w * 32 + (lane & 31);
     const int keyc = min(key, S - 1);
     const size_t rowbase = (size_t)n * S;
     STAMP_DECL
@@ -444,13 +483,9 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             diag_step<7>(s, j, all, wrapped);   diag_step<8>(s, j, all, wrapped);   diag_step<9>(s, j, all, wrapped);
             diag_step<10>(s, j, all, wrapped);  diag_step<11>(s, j, all, wrapped);  diag_step<12>(s, j, all, wrapped);
             diag_step<13>(s, j, all, wrapped);  diag_step<14>(s, j, all, wrapped);  diag_step<15>(s, j, all, wrapped);
-            const int idx = (blockIdx.x * 128 + w * 32 + j) - qt * 32 + S - 1 - 4 * hh;      // diagonal of lane j
-#ifndef DBG_NO_LATOMIC
+            const int idx = (bx * 128 + w * 32 + j) - qt * 32 + S - 1 - 4 * hh;      // diagonal of lane j
             if (idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], (all - wrapped) + carry);
             carry = wrapped;
-#else
-            carry += all - wrapped;
-#endif
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -482,18 +517,14 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     }
     STAMP(12);
     if (a.dbias) {
-        const int idx = (blockIdx.x * 128 + w * 32 + (lane & 31)) - ntile * 32 + S - 1 - 4 * hh;   // wrapped part of the last tile
+        const int idx = (bx * 128 + w * 32 + (lane & 31)) - ntile * 32 + S - 1 - 4 * hh;   // wrapped part of the last tile
         if (idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], carry);
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * S - 1; i += 256) {
             const float v = ldb[i];
             // every workgroup of a head adds to the same 2S-1 words; replicas keep same-address atomics apart
             const int rep = (blockIdx.z * gridDim.x + blockIdx.x) % a.dbias_replicas;
-#ifndef DBG_NO_GATOMIC
             if (v != 0.f) atomicAdd(a.dbias + ((size_t)rep * a.H + h) * (2 * S - 1) + i, v);
-#else
-            if (v == 123.f) a.dbias[i] = v;
-#endif
         }
     }
     STAMP(13); STAMP(14);
@@ -516,8 +547,9 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
     char* lVr = smem + 16384;       // row image of V
     float* lbias = reinterpret_cast<float*>(smem + 24576);    // 2S + 64
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5;
-    const int n = blockIdx.z, h = blockIdx.y, S = a.S;
-    const int q = blockIdx.x * 128 + w * 32 + (lane & 31);
+    const BlockId blk = block_of(gridDim.x, a.H, a.N);
+    const int n = blk.n, h = blk.h, S = a.S;
+    const int q = blk.x * 128 + w * 32 + (lane & 31);
     const int qc = min(q, S - 1);
     const size_t rowbase = (size_t)n * S;
 #ifdef DBG_STAMPS_DKDV
@@ -532,22 +564,33 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
     const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * DK, a.ld, S, DK);
     const __amdgpu_buffer_rsrc_t rO = rows_rsrc(a.o + rowbase * a.ldo + h * DK, a.ldo, S, DK);
     const __amdgpu_buffer_rsrc_t rD = rows_rsrc(a.dout + rowbase * a.lddo + h * DK, a.lddo, S, DK);
-    bf16x8 qf[4], dof[4], of[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = bload8(rQ, (qc * a.ld + 16 * ks + 8 * hh) * 2);
-        dof[ks] = bload8(rD, (qc * a.lddo + 16 * ks + 8 * hh) * 2);
-        of[ks] = bload8(rO, (qc * a.ldo + 16 * ks + 8 * hh) * 2);
-    }
+    // this workgroup's 128 rows of Q, dO and O, fetched by whole rows and turned into fragments through LDS
+    const int q0 = blk.x * 128;
+    const Tile128 tq = load_tile128(rQ, a.ld, q0), td = load_tile128(rD, a.lddo, q0), to = load_tile128(rO, a.ldo, q0);
     const float lse = bloadf(floats_rsrc(a.lse + ((size_t)n * a.H + h) * S, S), qc);
     Tile64 kreg = load_tile64(rK, a.ld, 0), vreg = load_tile64(rV, a.ld, 0);
+    const int ntile = (S + 63) / 64;
     stage_bias(floats_rsrc(a.bias ? a.bias + (size_t)h * (2 * S - 1) : nullptr, 2 * S - 1), lbias, 0, 2 * S + 64);
-    float delta = 0.f;
+    float* ldelta = lbias + (2 * S + 64);                 // 128: rowsum(dO * O) of the workgroup's rows
+    store_tile128(tq, smem);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int i = 0; i < 4; ++i) {
+        float d = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) delta += bf2f(dof[ks][j]) * bf2f(of[ks][j]);
-    delta += __shfl_xor(delta, 32, 64);
+        for (int j = 0; j < 8; ++j) d += bf2f(td.v[i][j]) * bf2f(to.v[i][j]);
+        d += lane_xor1(d); d += lane_xor2(d); d += lane_mirror8(d);       // sum over the row's 8 threads
+        if ((threadIdx.x & 7) == 0) ldelta[(threadIdx.x + i * 256) >> 3] = d;
+    }
+    __syncthreads();
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_rows(smem, 32 * w, ks, lane);
+    const float delta = ldelta[32 * w + (lane & 31)];
+    __syncthreads();
+    store_tile128(td, smem);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dof[ks] = frag_rows(smem, 32 * w, ks, lane);
 
     f32x16 dq0, dq1, zero16;
 #pragma unroll
@@ -560,7 +603,6 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
     // hash quad number of (this lane's query, keys 4*hh ..): + 2 per register group, + 8 per 32 keys
     const uint64_t hq = (((((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3)) >> 2) + hh;
 
-    const int ntile = (S + 63) / 64;
     for (int kt = 0; kt < ntile; ++kt) {
         if (kt < 4) STAMP(2 + 3 * kt);
         __syncthreads();
@@ -1163,8 +1205,9 @@ extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, i
     a.out = (bf16*)ctx; a.ldo = ldo; a.lse = lse; a.bias = bias_tbl;
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const size_t smem = 16384 + (size_t)(2 * S + 64) * 4;
-    if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_fwd_kernel<true>), dim3((S + 127) / 128, H, N), dim3(256), smem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((enc_attn_fwd_kernel<false>), dim3((S + 127) / 128, H, N), dim3(256), smem, (hipStream_t)stream, a);
+    const dim3 grid((S + 127) / 128, H, N);
+    if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_fwd_kernel<true>), grid, dim3(256), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((enc_attn_fwd_kernel<false>), grid, dim3(256), smem, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }
@@ -1188,7 +1231,7 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
     if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<true>), grid, dim3(256), smem1, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<false>), grid, dim3(256), smem1, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
-    const size_t smem2 = 24576 + (size_t)(2 * S + 64) * 4;
+    const size_t smem2 = 24576 + (size_t)(2 * S + 64 + 128) * 4;
     if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<true>), grid, dim3(256), smem2, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<false>), grid, dim3(256), smem2, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();

@@ -12,6 +12,6 @@ import csv, glob
 f = glob.glob("/tmp/prof_$lib/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
     if "enc_attn" in r["Name"]:
-        print(f"  {r['Name'][:48]:48s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:8.1f} us  min {float(r['MinNs'])/1e3:8.1f}")
+        print(f"  {r['Name'][:56]:56s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:8.1f} us  min {float(r['MinNs'])/1e3:8.1f}")
 PY
 done
