@@ -58,6 +58,22 @@ int paced_gemm_bf16(const void* A, const void* B, void* C, const void* aux,
                     int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
                     float drop_p, uint32_t drop_seed, int splits, void* stream);
 
+/* paced_gemm_bf16 with HEAD-MAJOR operands.  A head-major operand (its stride argument > 0, its leading dimension 64)
+ * stores the feature columns [64h, 64h + 64) as the contiguous [rows, 64] matrix at base + h * stride (elements) -- the
+ * layout HF's T5Attention gives its projected states before the attention product (modeling_t5.py `shape()`:
+ * view(batch, -1, n_heads, d_kv).transpose(1, 2)) -- so that one head of one sequence is one contiguous block for the
+ * attention kernels below instead of 128-byte pieces at a row stride.  A: features = K (trans_a = 0) or M (trans_a = 1);
+ * B: transposed only, features = N; C: plain bf16 epilogue only, features = N.  Feature counts are multiples of 64, the
+ * stride is at least rows * 64.  Of a transposed A and B at most one may be head-major; when its row count (the
+ * contraction length) is not a multiple of 64, the last step reads up to 63 rows past it -- the padding or the next
+ * head's rows, zeros past the last head -- which must hold finite values: they meet the other operand's zeros.
+ * Same bits as paced_gemm_bf16 on the same values. */
+int paced_gemm_bf16_heads(const void* A, const void* B, void* C, const void* aux,
+                          int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                          int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
+                          float drop_p, uint32_t drop_seed, int splits,
+                          long long a_heads, long long b_heads, long long c_heads, void* stream);
+
 /* `batch` independent products of the same shape in one launch: member b uses A + b*strideA, B + b*strideB,
  * C + b*strideC (strides in elements, multiples of 8).  Epilogues 0 (bf16), 4 (fp32) and 5 (fp32 atomic) only.
  * Serves the per-head products of the decoder's cross-attention (HF modeling_t5.py:459-498 computes them as one
@@ -113,16 +129,18 @@ int paced_relbias_table_fwd(const void* rel_bias, const int* bucket, float* tbl,
 int paced_relbias_table_bwd(const float* dtbl, int replicas, const int* bucket, float* drel_bias, int H, int L, void* stream);
 
 /* ---- encoder self-attention, HF:144-173 with scaling = 1.0 (HF:196-197), no mask (lceT5.py:53) ----
- * q,k,v: rows (n*S+s), head h at columns [h*64, h*64+64), row stride ld.  ctx [N*S, ldo];
+ * Every matrix (q, k, v | ctx | dctx | dq, dk, dv) is addressed by a row stride and a head stride: row (n*S+s) of head h
+ * starts at element (n*S+s)*ld + h*hs; hs = 64 for heads side by side in rows of ld elements, or ld = 64 and
+ * hs >= rows * 64 for head-major matrices (paced_gemm_bf16_heads writes and reads those).
  * lse [N,H,S] fp32 (log-sum-exp of the biased scores); bias_tbl [H, 2S-1] fp32 or NULL.
  * bwd writes dq, dk, dv (same addressing, row stride ldd) and adds into dbias_tbl (may be NULL):
  * [dbias_replicas, H, 2S-1]; workgroups spread their adds over the replicas so that same-address
  * atomics do not serialise; the caller sums the replicas (paced_relbias_table_bwd does). */
-int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, void* ctx, int ldo, float* lse,
+int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, long long hs, void* ctx, int ldo, long long hso, float* lse,
                        const float* bias_tbl, int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
-int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* ctx, int ldo,
-                       const void* dctx, int lddo, const float* lse, const float* bias_tbl,
-                       void* dq, void* dk_, void* dv, int ldd, float* dbias_tbl, int dbias_replicas,
+int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, long long hs, const void* ctx, int ldo, long long hso,
+                       const void* dctx, int lddo, long long hsdo, const float* lse, const float* bias_tbl,
+                       void* dq, void* dk_, void* dv, int ldd, long long hsd, float* dbias_tbl, int dbias_replicas,
                        int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
 
 /* ---- decoder attention for the 2-token target, HF:459-498 ---------------------------------------

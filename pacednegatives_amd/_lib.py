@@ -20,6 +20,7 @@ SIGNATURES = {
     "paced_abi_version": (_i, []),
     "paced_last_error": (C.c_char_p, []),
     "paced_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _u32, _i, _vp]),
+    "paced_gemm_bf16_heads": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _u32, _i, _ll, _ll, _ll, _vp]),
     "paced_gemm_bf16_batched": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _ll, _ll, _ll, _vp]),
     "paced_gemm_set_tile": (_i, [_i]),
     "paced_gemm_set_ring": (_i, [_i]),
@@ -33,8 +34,8 @@ SIGNATURES = {
     "paced_cast_f32_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "paced_relbias_table_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "paced_relbias_table_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
-    "paced_enc_attn_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _u32, _vp]),
-    "paced_enc_attn_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp]),
+    "paced_enc_attn_fwd": (_i, [_vp, _vp, _vp, _i, _ll, _vp, _i, _ll, _vp, _vp, _i, _i, _i, _i, _f, _u32, _vp]),
+    "paced_enc_attn_bwd": (_i, [_vp, _vp, _vp, _i, _ll, _vp, _i, _ll, _vp, _i, _ll, _vp, _vp, _vp, _vp, _vp, _i, _ll, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp]),
     "paced_dec_self_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _u32, _vp]),
     "paced_dec_self_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _u32, _vp]),
     "paced_cross_attn_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _u32, _vp]),

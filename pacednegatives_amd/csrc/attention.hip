@@ -132,12 +132,13 @@ __device__ __forceinline__ BlockId block_of(int nx, int H, int N) {
 }
 
 struct AttnArgs {
-    const bf16* q; const bf16* k; const bf16* v;   // row (n*S + s), head h at column h*64; row stride ld
-    int ld;
-    const bf16* o; int ldo;                        // forward output / saved context
-    const bf16* dout; int lddo;
-    bf16* out;                                     // fwd: context
-    bf16* dq; bf16* dk; bf16* dv; int ldd;         // bwd outputs, same addressing as q/k/v
+    // Every matrix: row (n*S + s) of head h starts at element (n*S + s)*ld + h*hs.  hs = 64: the heads side by side in
+    // rows of ld elements; head-major: ld = 64, hs >= rows * 64 (a (sequence, head) is then one contiguous block).
+    const bf16* q; const bf16* k; const bf16* v; int ld; long long hs;
+    const bf16* o; int ldo; long long hso;         // forward output / saved context (bwd)
+    const bf16* dout; int lddo; long long hsdo;
+    bf16* out;                                     // fwd: context, addressed by ldo / hso
+    bf16* dq; bf16* dk; bf16* dv; int ldd; long long hsd;   // bwd outputs
     float* lse;                                    // [N, H, S]
     const float* bias;                             // [H, 2S-1], index key - query + S - 1 (may be null)
     float* dbias;                                  // [R, H, 2S-1] fp32 atomics, R replicas (may be null)
@@ -227,9 +228,9 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     const int qc = min(q, S - 1);
     const size_t rowbase = (size_t)n * S;
     // every global load of the prologue is issued before the first wait: one memory round trip, not one per operand
-    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * DK, a.ld, S, DK);
-    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * DK, a.ld, S, DK);
-    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * DK, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * a.hs, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * a.hs, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * a.hs, a.ld, S, DK);
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = bload8(rQ, (qc * a.ld + 16 * ks + 8 * hh) * 2);
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     const float inv = (DROP ? a.drop.scale : 1.f) / l_tot;
     if (q < S) {
         if (hh == 0 && a.lse) a.lse[((size_t)n * a.H + h) * S + q] = m_run + __logf(l_tot);
-        bf16* orow = a.out + (rowbase + q) * a.ldo + h * DK;
+        bf16* orow = a.out + (rowbase + q) * a.ldo + h * a.hso;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             bf16x4 v0, v1;
@@ -368,11 +369,11 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     STAMP_DECL
     STAMP(0); STAMP(1);
     // every global load of the prologue is issued before the first wait; rows past S read as zeros
-    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * DK, a.ld, S, DK);
-    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * DK, a.ld, S, DK);
-    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * DK, a.ld, S, DK);
-    const __amdgpu_buffer_rsrc_t rO = rows_rsrc(a.o + rowbase * a.ldo + h * DK, a.ldo, S, DK);
-    const __amdgpu_buffer_rsrc_t rD = rows_rsrc(a.dout + rowbase * a.lddo + h * DK, a.lddo, S, DK);
+    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * a.hs, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * a.hs, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * a.hs, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rO = rows_rsrc(a.o + rowbase * a.ldo + h * a.hso, a.ldo, S, DK);
+    const __amdgpu_buffer_rsrc_t rD = rows_rsrc(a.dout + rowbase * a.lddo + h * a.hsdo, a.lddo, S, DK);
     const __amdgpu_buffer_rsrc_t rL = floats_rsrc(a.lse + ((size_t)n * a.H + h) * S, S);
     bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -499,8 +500,8 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     }
     STAMP(11);
     if (key < S) {
-        bf16* dkrow = a.dk + (rowbase + key) * a.ldd + h * DK;
-        bf16* dvrow = a.dv + (rowbase + key) * a.ldd + h * DK;
+        bf16* dkrow = a.dk + (rowbase + key) * a.ldd + h * a.hsd;
+        bf16* dvrow = a.dv + (rowbase + key) * a.ldd + h * a.hsd;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             bf16x4 k0, k1, v0, v1;
@@ -559,11 +560,11 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
     STAMP(0); STAMP(1);
 
     // every global load of the prologue is issued before the first wait; rows past S read as zeros
-    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * DK, a.ld, S, DK);
-    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * DK, a.ld, S, DK);
-    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * DK, a.ld, S, DK);
-    const __amdgpu_buffer_rsrc_t rO = rows_rsrc(a.o + rowbase * a.ldo + h * DK, a.ldo, S, DK);
-    const __amdgpu_buffer_rsrc_t rD = rows_rsrc(a.dout + rowbase * a.lddo + h * DK, a.lddo, S, DK);
+    const __amdgpu_buffer_rsrc_t rQ = rows_rsrc(a.q + rowbase * a.ld + h * a.hs, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rK = rows_rsrc(a.k + rowbase * a.ld + h * a.hs, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rV = rows_rsrc(a.v + rowbase * a.ld + h * a.hs, a.ld, S, DK);
+    const __amdgpu_buffer_rsrc_t rO = rows_rsrc(a.o + rowbase * a.ldo + h * a.hso, a.ldo, S, DK);
+    const __amdgpu_buffer_rsrc_t rD = rows_rsrc(a.dout + rowbase * a.lddo + h * a.hsdo, a.lddo, S, DK);
     // this workgroup's 128 rows of Q, dO and O, fetched by whole rows and turned into fragments through LDS
     const int q0 = blk.x * 128;
     const Tile128 tq = load_tile128(rQ, a.ld, q0), td = load_tile128(rD, a.lddo, q0), to = load_tile128(rO, a.ldo, q0);
@@ -657,7 +658,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
     STAMP_DUMP(a.dbias);
 #endif
     if (q < S) {
-        bf16* dqrow = a.dq + (rowbase + q) * a.ldd + h * DK;
+        bf16* dqrow = a.dq + (rowbase + q) * a.ldd + h * a.hsd;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             bf16x4 v0, v1;
@@ -1195,14 +1196,15 @@ int check_common(const char* fn, int N, int S, int H, int dk) {
 
 }  // namespace
 
-extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, void* ctx, int ldo, float* lse,
+extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, long long hs, void* ctx, int ldo, long long hso, float* lse,
                                   const float* bias_tbl, int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
     if (int e = check_common("paced_enc_attn_fwd", N, S, H, dk)) return e;
     PACED_CHECK_ARG(q && k && v && ctx, "paced_enc_attn_fwd: null operand");
-    PACED_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0, "paced_enc_attn_fwd: row strides must be multiples of 8");
+    PACED_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && hs % 8 == 0 && hs >= 64 && hso % 8 == 0 && hso >= 64,
+                    "paced_enc_attn_fwd: row strides must be multiples of 8, head strides multiples of 8 that are >= 64");
     AttnArgs a = {};
-    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
-    a.out = (bf16*)ctx; a.ldo = ldo; a.lse = lse; a.bias = bias_tbl;
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld; a.hs = hs;
+    a.out = (bf16*)ctx; a.ldo = ldo; a.hso = hso; a.lse = lse; a.bias = bias_tbl;
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const size_t smem = 16384 + (size_t)(2 * S + 64) * 4;
     const dim3 grid((S + 127) / 128, H, N);
@@ -1212,17 +1214,19 @@ extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, i
     return PACED_OK;
 }
 
-extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, const void* ctx, int ldo,
-                                  const void* dctx, int lddo, const float* lse, const float* bias_tbl,
-                                  void* dq, void* dk_, void* dv, int ldd, float* dbias_tbl, int dbias_replicas,
+extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, long long hs, const void* ctx, int ldo, long long hso,
+                                  const void* dctx, int lddo, long long hsdo, const float* lse, const float* bias_tbl,
+                                  void* dq, void* dk_, void* dv, int ldd, long long hsd, float* dbias_tbl, int dbias_replicas,
                                   int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
     if (int e = check_common("paced_enc_attn_bwd", N, S, H, dk)) return e;
     PACED_CHECK_ARG(q && k && v && ctx && dctx && lse && dq && dk_ && dv, "paced_enc_attn_bwd: null operand");
     PACED_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0, "paced_enc_attn_bwd: bad row strides");
+    PACED_CHECK_ARG(hs % 8 == 0 && hs >= 64 && hso % 8 == 0 && hso >= 64 && hsdo % 8 == 0 && hsdo >= 64 && hsd % 4 == 0 && hsd >= 64,
+                    "paced_enc_attn_bwd: head strides must be multiples of 8 (4 for the outputs) that are >= 64");
     AttnArgs a = {};
-    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld;
-    a.o = (const bf16*)ctx; a.ldo = ldo; a.dout = (const bf16*)dctx; a.lddo = lddo;
-    a.dq = (bf16*)dq; a.dk = (bf16*)dk_; a.dv = (bf16*)dv; a.ldd = ldd;
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld; a.hs = hs;
+    a.o = (const bf16*)ctx; a.ldo = ldo; a.hso = hso; a.dout = (const bf16*)dctx; a.lddo = lddo; a.hsdo = hsdo;
+    a.dq = (bf16*)dq; a.dk = (bf16*)dk_; a.dv = (bf16*)dv; a.ldd = ldd; a.hsd = hsd;
     PACED_CHECK_ARG(!dbias_tbl || dbias_replicas >= 1, "paced_enc_attn_bwd: dbias_replicas must be >= 1");
     a.lse = const_cast<float*>(lse); a.bias = bias_tbl; a.dbias = dbias_tbl; a.dbias_replicas = dbias_replicas;
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);

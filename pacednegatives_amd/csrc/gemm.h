@@ -23,6 +23,11 @@ struct GemmParams {
     int M, N, K;
     int lda, ldb, ldc, ldaux;
     int k_per_split;   // multiple of BK
+    // Head-major operands (> 0: elements between heads; the operand's leading dimension is then 64): the operand's feature
+    // columns [64h, 64h + 64) are the contiguous [rows, 64] matrix at base + h * stride instead of a column block of rows of
+    // ld elements.  A: features = K (not transposed) or M (transposed); B: transposed only, features = N; C: plain bf16
+    // epilogue only, features = N.
+    long long a_heads, b_heads, c_heads;
     int batch;         // independent problems of the same shape; operand b starts strideX * b elements after operand 0
     long long strideA, strideB, strideC;
     float alpha;       // scales acc before the epilogue

@@ -57,7 +57,7 @@ namespace {
 // half holds one 32-row block out of every 64 rows, so that a wave's two 32-row slices (one per half)
 // are 64 CONSECUTIVE tile rows.
 template <bool TRANS, int ROWS, bool SPLIT = false>
-__device__ __forceinline__ uint32_t stage_offset(int g, int ld) {
+__device__ __forceinline__ uint32_t stage_offset(int g, int ld, long long heads = 0) {
     if (!TRANS) {
         const int r = g >> 3, cs = g & 7;
         const int c = cs ^ ((r >> 1) & 7);
@@ -69,6 +69,7 @@ __device__ __forceinline__ uint32_t stage_offset(int g, int ld) {
         const int hk = ((k & 3) | (((k >> 3) & 1) << 2)) & (ROWS / 16 - 1);
         const int c = (((cs >> 1) ^ hk) << 1) | (cs & 1);
         const int csrc = SPLIT ? ((c >> 2) * 8 + (c & 3)) : c;
+        if (heads) return (uint32_t)(((csrc >> 3) * heads + k * 64 + (csrc & 7) * 8) * 2);      // head-major: 8 chunks per head
         return (uint32_t)(k * ld + csrc * 8) * 2u;
     }
 }
@@ -116,7 +117,7 @@ __device__ __forceinline__ void store_quad(const GemmParams& p, void* Cb, int m,
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = a[r] * p.alpha;
-    const size_t ci = (size_t)m * p.ldc + n;
+    const size_t ci = (EPI == EPI_BF16 && p.c_heads) ? (size_t)(n >> 6) * p.c_heads + (size_t)m * 64 + (n & 63) : (size_t)m * p.ldc + n;
     const uint64_t di = (uint64_t)m * (uint64_t)p.N + n;   // dropout counter: logical (row, col)
     if (EPI == EPI_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cb) + ci) = f32x4{v[0], v[1], v[2], v[3]};
@@ -238,12 +239,20 @@ __device__ __forceinline__ WorkItem decode_item(const GemmParams& p, int L, int 
     // Buffer descriptors: base at the tile's first row (or column), range = exactly the valid bytes,
     // so rows >= M/N and contraction rows >= K read as zero.
     const int rowsA = min(BM, p.M - it.m0), rowsB = min(BN, p.N - it.n0);
-    const bf16* baseA = p.A + (long long)it.b * p.strideA + (TA ? (size_t)it.m0 : (size_t)it.m0 * p.lda);
-    const bf16* baseB = p.B + (long long)it.b * p.strideB + (TB ? (size_t)it.n0 : (size_t)it.n0 * p.ldb);
+    const bf16* baseA = p.A + (long long)it.b * p.strideA + (TA ? (p.a_heads ? (size_t)(it.m0 >> 6) * p.a_heads : (size_t)it.m0) : (size_t)it.m0 * p.lda);
+    const bf16* baseB = p.B + (long long)it.b * p.strideB + (TB ? (p.b_heads ? (size_t)(it.n0 >> 6) * p.b_heads : (size_t)it.n0) : (size_t)it.n0 * p.ldb);
     // (a transposed A whose M is not a multiple of 8: the last 16-byte piece of a contraction row straddles M; it is kept
     // in range, lda >= M rounded up to 8 guarantees the bytes exist, and the output rows >= M it feeds are never stored)
-    const uint32_t recA = TA ? (uint32_t)(((size_t)(p.K - 1) * p.lda + ((rowsA + 7) & ~7)) * 2) : (uint32_t)(((size_t)(rowsA - 1) * p.lda + p.K) * 2);
-    const uint32_t recB = TB ? (uint32_t)(((size_t)(p.K - 1) * p.ldb + rowsB) * 2) : (uint32_t)(((size_t)(rowsB - 1) * p.ldb + p.K) * 2);
+    // Head-major operands: the range runs to the end of the operand's last head.  What a ragged tile reads past its own
+    // rows is then the next head's data (finite) instead of zeros: output rows past M are never stored, and a contraction
+    // row past K meets the other operand's zeros (only one operand of a product may be head-major and transposed).
+    const uint32_t recA = TA ? (p.a_heads ? (uint32_t)(((size_t)((p.M + 63) / 64 - 1 - (it.m0 >> 6)) * p.a_heads + (size_t)p.K * 64) * 2)
+                                          : (uint32_t)(((size_t)(p.K - 1) * p.lda + ((rowsA + 7) & ~7)) * 2))
+                        : p.a_heads ? (uint32_t)(((size_t)(p.K / 64 - 1) * p.a_heads + (size_t)rowsA * 64) * 2)
+                        : (uint32_t)(((size_t)(rowsA - 1) * p.lda + p.K) * 2);
+    const uint32_t recB = TB ? (p.b_heads ? (uint32_t)(((size_t)((p.N + 63) / 64 - 1 - (it.n0 >> 6)) * p.b_heads + (size_t)p.K * 64) * 2)
+                                          : (uint32_t)(((size_t)(p.K - 1) * p.ldb + rowsB) * 2))
+                        : (uint32_t)(((size_t)(rowsB - 1) * p.ldb + p.K) * 2);
     it.rA = __builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, recA, 0x00020000);
     it.rB = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, recB, 0x00020000);
     return it;
@@ -382,10 +391,10 @@ __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_bf16_kernel(Gem
 
     uint32_t offA[Ops::IA], offB[Ops::IB];
 #pragma unroll
-    for (int i = 0; i < Ops::IA; ++i) offA[i] = stage_offset<TA, BM>((i * NW + w) * 64 + lane, p.lda);
+    for (int i = 0; i < Ops::IA; ++i) offA[i] = stage_offset<TA, BM>((i * NW + w) * 64 + lane, p.lda, p.a_heads);
 #pragma unroll
-    for (int i = 0; i < Ops::IB; ++i) offB[i] = stage_offset<TB, BN>((i * NW + w) * 64 + lane, p.ldb);
-    const uint32_t kstrideA = TA ? (uint32_t)p.lda * 2u : 2u;
+    for (int i = 0; i < Ops::IB; ++i) offB[i] = stage_offset<TB, BN>((i * NW + w) * 64 + lane, p.ldb, p.b_heads);
+    const uint32_t kstrideA = TA ? (uint32_t)p.lda * 2u : p.a_heads ? (uint32_t)(p.a_heads / 32) : 2u;   // bytes per contraction index
     const uint32_t kstrideB = TB ? (uint32_t)p.ldb * 2u : 2u;
 
     int L = item_of(b, 0, G, total_items);
@@ -452,10 +461,10 @@ __global__ void __launch_bounds__(Cfg::WGM * Cfg::WGN * 64) gemm_ring_kernel(Gem
 
     uint32_t offA[Ops::IA], offB[Ops::IB];
 #pragma unroll
-    for (int i = 0; i < Ops::IA; ++i) offA[i] = stage_offset<TA, BM>((i * NW + w) * 64 + lane, p.lda);
+    for (int i = 0; i < Ops::IA; ++i) offA[i] = stage_offset<TA, BM>((i * NW + w) * 64 + lane, p.lda, p.a_heads);
 #pragma unroll
-    for (int i = 0; i < Ops::IB; ++i) offB[i] = stage_offset<TB, BN>((i * NW + w) * 64 + lane, p.ldb);
-    const uint32_t kstrideA = TA ? (uint32_t)p.lda * 2u : 2u;
+    for (int i = 0; i < Ops::IB; ++i) offB[i] = stage_offset<TB, BN>((i * NW + w) * 64 + lane, p.ldb, p.b_heads);
+    const uint32_t kstrideA = TA ? (uint32_t)p.lda * 2u : p.a_heads ? (uint32_t)(p.a_heads / 32) : 2u;   // bytes per contraction index
     const uint32_t kstrideB = TB ? (uint32_t)p.ldb * 2u : 2u;
 
     const WorkItem it = decode_item<Cfg, TA, TB>(p, xcd_remap(blockIdx.x, total_items), ntm, ntn);
@@ -696,7 +705,9 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
             for (int e = 0; e < 8; ++e) byte |= (bf2f(t[e]) > 0.f ? 1u : 0u) << e;
             const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (ncol >> 3)] = (unsigned char)byte;
         }
-        if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
+        if (EPI == EPI_BF16 && p.c_heads) {        // a wave's 64 columns are one head: rows of 128 bytes, 128 bytes apart
+            if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)(ncol >> 6) * p.c_heads + (size_t)m * 64 + (ncol & 63)) = t;
+        } else if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
         if (LOADS && n < 8) {
             if (FULL) load_piece(n + 8);
             else if (n == 7) {
@@ -745,12 +756,13 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
     uint32_t offA[2], offB[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        offA[i] = stage_offset<TA, 128>((i * 8 + w) * 64 + lane, p.lda);
-        offB[i] = stage_offset<TB, 128, true>((i * 8 + w) * 64 + lane, p.ldb);
+        offA[i] = stage_offset<TA, 128>((i * 8 + w) * 64 + lane, p.lda, p.a_heads);
+        offB[i] = stage_offset<TB, 128, true>((i * 8 + w) * 64 + lane, p.ldb, p.b_heads);
     }
-    const uint32_t kstrideA = TA ? (uint32_t)p.lda * 2u : 2u;
+    const uint32_t kstrideA = TA ? (uint32_t)p.lda * 2u : p.a_heads ? (uint32_t)(p.a_heads / 32) : 2u;   // bytes per contraction index
     const uint32_t kstrideB = TB ? (uint32_t)p.ldb * 2u : 2u;
-    const uint32_t halfA = TA ? 256u : 256u * (uint32_t)p.lda;      // bytes from half 0 to half 1 (128 rows)
+    // bytes from half 0 to half 1 (128 rows; of a transposed head-major A: two heads on)
+    const uint32_t halfA = TA ? (p.a_heads ? (uint32_t)(p.a_heads * 4) : 256u) : 256u * (uint32_t)p.lda;
     const uint32_t halfB = TB ? 64u : 64u * (uint32_t)p.ldb;          // B half 1 starts 32 rows after half 0
     char* const sw = smem + w * 1024;                                // this wave's slice of a half-tile image
 
@@ -1051,8 +1063,20 @@ static int gemm_entry(const void* A, const void* B, void* C, const void* aux,
                       int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
                       int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
                       float drop_p, uint32_t drop_seed, int splits, void* stream,
-                      int batch, long long strideA, long long strideB, long long strideC) {
+                      int batch, long long strideA, long long strideB, long long strideC,
+                      long long a_heads = 0, long long b_heads = 0, long long c_heads = 0) {
     PACED_CHECK_ARG(A && B && C, "paced_gemm_bf16: null operand");
+    if (a_heads || b_heads || c_heads) {
+        PACED_CHECK_ARG(batch == 1 && a_heads >= 0 && b_heads >= 0 && c_heads >= 0 && a_heads % 64 == 0 && b_heads % 64 == 0 && c_heads % 8 == 0,
+                        "paced_gemm_bf16_heads: head strides must be non-negative multiples of 64 (A, B) / 8 (C); no batches");
+        const long long a_rows = trans_a ? K : M, a_feat = trans_a ? M : K;
+        if (a_heads) PACED_CHECK_ARG(lda == 64 && a_feat % 64 == 0 && a_heads >= a_rows * 64 && (size_t)(a_feat / 64) * a_heads * 2 < 0xFFFFFFF0ull,
+                                     "paced_gemm_bf16_heads: a head-major A needs lda = 64, a feature count that is a multiple of 64 and heads >= rows * 64 elements apart (below 4 GB in all)");
+        if (b_heads) PACED_CHECK_ARG(trans_b && ldb == 64 && N % 64 == 0 && b_heads >= (long long)K * 64 && (size_t)(N / 64) * b_heads * 2 < 0xFFFFFFF0ull && !(a_heads && trans_a),
+                                     "paced_gemm_bf16_heads: a head-major B must be the transposed operand (ldb = 64, N %% 64 == 0, heads >= K * 64 apart), and not beside a transposed head-major A");
+        if (c_heads) PACED_CHECK_ARG(epilogue == EPI_BF16 && N % 64 == 0 && c_heads >= (long long)M * 64,
+                                     "paced_gemm_bf16_heads: a head-major C needs the plain bf16 epilogue, N %% 64 == 0 and heads >= M * 64 elements apart");
+    }
     PACED_CHECK_ARG(batch >= 1 && batch <= 65536, "paced_gemm_bf16_batched: batch must be in 1..65536 (got %d)", batch);
     if (batch > 1) {
         PACED_CHECK_ARG(epilogue == EPI_BF16 || epilogue == EPI_F32 || epilogue == EPI_ATOMIC_F32,
@@ -1069,7 +1093,7 @@ static int gemm_entry(const void* A, const void* B, void* C, const void* aux,
                     "paced_gemm_bf16: operands must be 16-byte aligned");
     if (!trans_a) PACED_CHECK_ARG(K % 64 == 0, "paced_gemm_bf16: K must be a multiple of 64 for a K-contiguous A");
     if (!trans_b) PACED_CHECK_ARG(K % 64 == 0, "paced_gemm_bf16: K must be a multiple of 64 for a K-contiguous B");
-    if (trans_a) PACED_CHECK_ARG((size_t)K * lda * 2 < 0xFFFFFFF0ull && lda >= ((M + 7) & ~7),
+    if (trans_a && !a_heads) PACED_CHECK_ARG((size_t)K * lda * 2 < 0xFFFFFFF0ull && lda >= ((M + 7) & ~7),
                                  "paced_gemm_bf16: transposed A too large for 32-bit offsets, or lda below M rounded up to a multiple of 8");
     if (trans_b) PACED_CHECK_ARG((size_t)K * ldb * 2 < 0xFFFFFFF0ull && N % 8 == 0, "paced_gemm_bf16: transposed B too large for 32-bit offsets or N%%8");
     if (!trans_a) PACED_CHECK_ARG((size_t)128 * lda * 2 < 0x7FFFFFFFull, "paced_gemm_bf16: lda too large");
@@ -1085,7 +1109,7 @@ static int gemm_entry(const void* A, const void* B, void* C, const void* aux,
     GemmParams p;
     p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.aux = (const bf16*)aux;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
-    p.k_per_split = K;
+    p.k_per_split = K; p.a_heads = a_heads; p.b_heads = b_heads; p.c_heads = c_heads;
     p.alpha = alpha; p.mask_scale = mask_scale;
     p.drop = make_drop(drop_p, drop_seed);
     p.tk_cand = nullptr; p.tk_cnt = nullptr; p.tk_thr = nullptr; p.tk_cap = 0; p.tk_row_base = 0;
@@ -1099,6 +1123,15 @@ extern "C" int paced_gemm_bf16(const void* A, const void* B, void* C, const void
                                float drop_p, uint32_t drop_seed, int splits, void* stream) {
     return gemm_entry(A, B, C, aux, M, N, K, lda, ldb, ldc, ldaux, trans_a, trans_b, epilogue, alpha, mask_scale,
                       drop_p, drop_seed, splits, stream, 1, 0, 0, 0);
+}
+
+extern "C" int paced_gemm_bf16_heads(const void* A, const void* B, void* C, const void* aux,
+                                     int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                                     int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
+                                     float drop_p, uint32_t drop_seed, int splits,
+                                     long long a_heads, long long b_heads, long long c_heads, void* stream) {
+    return gemm_entry(A, B, C, aux, M, N, K, lda, ldb, ldc, ldaux, trans_a, trans_b, epilogue, alpha, mask_scale,
+                      drop_p, drop_seed, splits, stream, 1, 0, 0, 0, a_heads, b_heads, c_heads);
 }
 
 extern "C" int paced_gemm_bf16_batched(const void* A, const void* B, void* C,

@@ -42,24 +42,35 @@ def _rows2d(t, name):
     return t.stride(0)
 
 
+def _operand(t, name):
+    """(rows, features, leading dimension, head stride) of a GEMM operand: a matrix [rows, features], or head-major
+    [features/64, rows, 64] (contiguous [rows, 64] members; head stride 0 means "not head-major")."""
+    if t.dim() == 3:
+        if t.shape[2] != 64 or t.stride(2) != 1 or t.stride(1) != 64:
+            raise ValueError(f"{name}: a head-major operand is [features/64, rows, 64] with contiguous [rows, 64] members, got {tuple(t.shape)} strides {t.stride()}")
+        return t.shape[1], t.shape[0] * 64, 64, t.stride(0)
+    return t.shape[0], t.shape[1], _rows2d(t, name), 0
+
+
 def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, alpha=1.0, mask_scale=1.0,
          drop_p=0.0, drop_seed=0, splits=1):
     """c = alpha * op(a) op(b) with a fused epilogue (see include/paced_hip.h).
 
     aux is the bf16 residual / mask operand of EPI_RES_DROP / EPI_MASK, or a uint8 [M, N/8] bit matrix
     (bit n%8 of byte n//8 of row m <-> element (m, n)): written by EPI_RELU_DROP with the sign of its
-    output, read by EPI_MASK_BITS.
+    output, read by EPI_MASK_BITS.  a, c and a transposed b may be head-major 3-D tensors (see _operand).
     """
     lib = _lib.load()
     bits = epilogue in (EPI_RELU_DROP, EPI_MASK_BITS)
     _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(aux, U8 if bits else BF16, "aux")
     _chk(c, F32 if epilogue in (EPI_F32, EPI_ATOMIC_F32) else BF16, "c")
-    lda, ldb, ldc = _rows2d(a, "a"), _rows2d(b, "b"), _rows2d(c, "c")
-    M, N = c.shape
-    K = a.shape[0] if trans_a else a.shape[1]
-    if (a.shape[1] if trans_a else a.shape[0]) != M:
+    ar, af, lda, ah = _operand(a, "a")
+    br, bf_, ldb, bh = _operand(b, "b")
+    M, N, ldc, ch = _operand(c, "c")
+    K = ar if trans_a else af
+    if (af if trans_a else ar) != M:
         raise ValueError(f"a {tuple(a.shape)} does not give M={M} (trans_a={trans_a})")
-    if (b.shape[1] if trans_b else b.shape[0]) != N or (b.shape[0] if trans_b else b.shape[1]) != K:
+    if (bf_ if trans_b else br) != N or (br if trans_b else bf_) != K:
         raise ValueError(f"b {tuple(b.shape)} does not give N={N}, K={K} (trans_b={trans_b})")
     ldaux = 0
     if aux is not None:
@@ -72,9 +83,14 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.paced_gemm_bf16(_p(a), _p(b), _p(c), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
-                                   int(trans_a), int(trans_b), epilogue, alpha, mask_scale, drop_p, drop_seed, splits,
-                                   _stream()), "paced_gemm_bf16")
+    if ah or bh or ch:
+        _lib.check(lib.paced_gemm_bf16_heads(_p(a), _p(b), _p(c), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
+                                             int(trans_a), int(trans_b), epilogue, alpha, mask_scale, drop_p, drop_seed, splits,
+                                             ah, bh, ch, _stream()), "paced_gemm_bf16_heads")
+    else:
+        _lib.check(lib.paced_gemm_bf16(_p(a), _p(b), _p(c), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
+                                       int(trans_a), int(trans_b), epilogue, alpha, mask_scale, drop_p, drop_seed, splits,
+                                       _stream()), "paced_gemm_bf16")
     if prof is not None:
         e1.record()
         prof.append(((int(trans_a), int(trans_b), int(epilogue), lib.paced_gemm_last_kernel()), 2.0 * M * N * K, e0, e1))
@@ -196,38 +212,49 @@ def relbias_table_bwd(dtbl, bucket, drel_bias):
     _lib.check(lib.paced_relbias_table_bwd(_p(dtbl), reps, _p(bucket), _p(drel_bias), H, L, _stream()), "paced_relbias_table_bwd")
 
 
+def _head_layout(ts, names, N, S, H):
+    """(row stride, head stride) shared by the given matrices: [N*S, H*64] (or column slices of one) with the heads side
+    by side, or head-major [H, N*S, 64] (what gemm writes into / reads from 3-D operands)."""
+    t0 = ts[0]
+    for t, n in zip(ts, names):
+        _chk(t, BF16, n)
+    if t0.dim() == 3:
+        for t in ts:
+            assert tuple(t.shape) == (H, N * S, 64) and t.stride(2) == 1 and t.stride(1) == 64 and t.stride(0) == t0.stride(0)
+        return 64, t0.stride(0)
+    ld = _rows2d(t0, names[0])
+    for t, n in zip(ts, names):
+        assert tuple(t.shape) == (N * S, H * 64) and _rows2d(t, n) == ld
+    return ld, 64
+
+
 def enc_attn_fwd(q, k, v, ctx, lse, bias_tbl, N, S, H, *, drop_p=0.0, drop_seed=0):
     lib = _lib.load()
-    for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx")):
-        _chk(t, BF16, n)
     _chk(lse, F32, "lse"); _chk(bias_tbl, F32, "bias_tbl")
-    ld = _rows2d(q, "q")
-    assert _rows2d(k, "k") == ld and _rows2d(v, "v") == ld
-    assert q.shape[0] == N * S and q.shape[1] == H * 64 and k.shape == q.shape and v.shape == q.shape
-    assert ctx.shape == q.shape and lse.numel() == N * H * S and lse.is_contiguous()
+    ld, hs = _head_layout((q, k, v), ("q", "k", "v"), N, S, H)
+    ldo, hso = _head_layout((ctx,), ("ctx",), N, S, H)
+    assert lse.numel() == N * H * S and lse.is_contiguous()
     assert bias_tbl is None or (tuple(bias_tbl.shape) == (H, 2 * S - 1) and bias_tbl.is_contiguous())
-    _lib.check(lib.paced_enc_attn_fwd(_p(q), _p(k), _p(v), ld, _p(ctx), _rows2d(ctx, "ctx"), _p(lse), _p(bias_tbl),
+    _lib.check(lib.paced_enc_attn_fwd(_p(q), _p(k), _p(v), ld, hs, _p(ctx), ldo, hso, _p(lse), _p(bias_tbl),
                                       N, S, H, 64, drop_p, drop_seed, _stream()), "paced_enc_attn_fwd")
     return ctx
 
 
 def enc_attn_bwd(q, k, v, ctx, dctx, lse, bias_tbl, dq, dk, dv, dbias_tbl, N, S, H, *, drop_p=0.0, drop_seed=0):
     lib = _lib.load()
-    for t, n in ((q, "q"), (k, "k"), (v, "v"), (ctx, "ctx"), (dctx, "dctx"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
-        _chk(t, BF16, n)
     _chk(lse, F32, "lse"); _chk(bias_tbl, F32, "bias_tbl"); _chk(dbias_tbl, F32, "dbias_tbl")
-    ld, ldd = _rows2d(q, "q"), _rows2d(dq, "dq")
-    assert _rows2d(k, "k") == ld and _rows2d(v, "v") == ld and _rows2d(dk, "dk") == ldd and _rows2d(dv, "dv") == ldd
-    for t in (q, k, v, ctx, dctx, dq, dk, dv):
-        assert tuple(t.shape) == (N * S, H * 64)
+    ld, hs = _head_layout((q, k, v), ("q", "k", "v"), N, S, H)
+    ldo, hso = _head_layout((ctx,), ("ctx",), N, S, H)
+    lddo, hsdo = _head_layout((dctx,), ("dctx",), N, S, H)
+    ldd, hsd = _head_layout((dq, dk, dv), ("dq", "dk", "dv"), N, S, H)
     assert lse.numel() == N * H * S and lse.is_contiguous()
     assert bias_tbl is None or (tuple(bias_tbl.shape) == (H, 2 * S - 1) and bias_tbl.is_contiguous())
     reps = 1
     if dbias_tbl is not None:
         assert dbias_tbl.is_contiguous() and tuple(dbias_tbl.shape[-2:]) == (H, 2 * S - 1) and dbias_tbl.dim() in (2, 3)
         reps = 1 if dbias_tbl.dim() == 2 else dbias_tbl.shape[0]
-    _lib.check(lib.paced_enc_attn_bwd(_p(q), _p(k), _p(v), ld, _p(ctx), _rows2d(ctx, "ctx"), _p(dctx), _rows2d(dctx, "dctx"),
-                                      _p(lse), _p(bias_tbl), _p(dq), _p(dk), _p(dv), ldd, _p(dbias_tbl), reps,
+    _lib.check(lib.paced_enc_attn_bwd(_p(q), _p(k), _p(v), ld, hs, _p(ctx), ldo, hso, _p(dctx), lddo, hsdo,
+                                      _p(lse), _p(bias_tbl), _p(dq), _p(dk), _p(dv), ldd, hsd, _p(dbias_tbl), reps,
                                       N, S, H, 64, drop_p, drop_seed, _stream()), "paced_enc_attn_bwd")
 
 

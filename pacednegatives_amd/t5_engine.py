@@ -132,6 +132,7 @@ class T5Engine:
         self.force_kv_projection = False      # tests: take the explicit K/V projection path of the cross-attention
         self.dw_stream = None                  # when set: weight-gradient products of backward() run on this stream
         self.ffn_bit_mask = os.environ.get("PACED_FFN_BITMASK", "1") != "0"   # encoder FFN backward masks by saved sign bits
+        self.head_major = os.environ.get("PACED_HEAD_MAJOR", "1") != "0"   # encoder attention operands head-major (see forward)
         self._bucket_dec = torch.tensor([0, 1], dtype=torch.int32, device=self.device)   # offsets 0 and -1 (HF:244-249)
         dec_b = relative_position_bucket(torch.tensor([0, -1]), False, dims.num_buckets, dims.max_distance)
         assert dec_b.tolist() == [0, 1]
@@ -157,6 +158,23 @@ class T5Engine:
 
     def _empty(self, rows, cols, dtype=BF16):
         return torch.empty(rows, cols, dtype=dtype, device=self.device)
+
+    def _heads(self, nheads, rows):
+        """Head-major bf16 matrix [nheads, rows, 64].  The weight-gradient products read such a matrix transposed, 64 rows
+        per step: rows are allocated up to a multiple of 64 and the padding is zeroed."""
+        alloc = (rows + 63) // 64 * 64
+        buf = torch.empty(nheads, alloc, 64, dtype=BF16, device=self.device)
+        if alloc != rows:
+            buf[:, rows:].zero_()
+        return buf[:, :rows]
+
+    @staticmethod
+    def _split_qkv(t, H):
+        """q, k, v parts of a fused projection output: [M, 3*H*64] rows, or head-major [3H, M, 64]."""
+        if t.dim() == 3:
+            return t[:H], t[H:2 * H], t[2 * H:]
+        I = H * 64
+        return t[:, :I], t[:, I:2 * I], t[:, 2 * I:]
 
     def _dweight(self, dy, x, name, rows: Optional[slice] = None):
         """grad[name] (+)= dy^T x  -- dy [M, out], x [M, in] -> [out, in], fp32 atomics."""
@@ -214,11 +232,16 @@ class T5Engine:
             sv = _EncLayerSaved()
             xn, rstd1 = self._empty(M, d), torch.empty(M, dtype=F32, device=self.device)
             K.rmsnorm_fwd(h, P.w(pre + "ln1"), xn, rstd1, eps=dims.eps)
-            qkv = self._empty(M, 3 * I)
+            # The attention's operands are head-major ([heads, M, 64]; the products write and read that layout): a
+            # (sequence, head) is one contiguous block for the attention kernels instead of 128-byte pieces at a row stride.
+            if self.head_major:
+                qkv, ctx = self._heads(3 * H, M), self._heads(H, M)
+            else:
+                qkv, ctx = self._empty(M, 3 * I), self._empty(M, I)
             K.gemm(xn, P.w(pre + "qkv"), qkv)
-            ctx = self._empty(M, I)
+            q_, k_, v_ = self._split_qkv(qkv, H)
             lse = torch.empty(N * H * S, dtype=F32, device=self.device)
-            K.enc_attn_fwd(qkv[:, :I], qkv[:, I:2 * I], qkv[:, 2 * I:], ctx, lse, st.bias_tbl, N, S, H,
+            K.enc_attn_fwd(q_, k_, v_, ctx, lse, st.bias_tbl, N, S, H,
                            drop_p=p, drop_seed=self._seed(st, _SITE_ATT, l))
             h_mid = self._empty(M, d)
             K.gemm(ctx, P.w(pre + "o"), h_mid, epilogue=K.EPI_RES_DROP, aux=h, drop_p=p, drop_seed=self._seed(st, _SITE_ATT_OUT, l))
@@ -455,11 +478,14 @@ class T5Engine:
                           drop2_p=p, drop2_seed=self._seed(st, _SITE_ATT_OUT, l))
             z = dz if dz is not None else dh_mid
             self._dweight(z, sv.ctx, pre + "o")
-            dctx = self._empty(M, I)
+            if sv.ctx.dim() == 3:       # head-major, like the saved context and q, k, v
+                dctx, dqkv = self._heads(H, M), self._heads(3 * H, M)
+            else:
+                dctx, dqkv = self._empty(M, I), self._empty(M, 3 * I)
             K.gemm(z, P.w(pre + "o"), dctx, trans_b=True)
-            dqkv = self._empty(M, 3 * I)
-            K.enc_attn_bwd(sv.qkv[:, :I], sv.qkv[:, I:2 * I], sv.qkv[:, 2 * I:], sv.ctx, dctx, sv.lse, st.bias_tbl,
-                           dqkv[:, :I], dqkv[:, I:2 * I], dqkv[:, 2 * I:], dbias_tbl, N, S, H,
+            q_, k_, v_ = self._split_qkv(sv.qkv, H)
+            dq_, dk_, dv_ = self._split_qkv(dqkv, H)
+            K.enc_attn_bwd(q_, k_, v_, sv.ctx, dctx, sv.lse, st.bias_tbl, dq_, dk_, dv_, dbias_tbl, N, S, H,
                            drop_p=p, drop_seed=self._seed(st, _SITE_ATT, l))
             self._dweight(dqkv, sv.xn, pre + "qkv")
             K.gemm(dqkv, P.w(pre + "qkv"), dxn, trans_b=True)

@@ -31,7 +31,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/paced_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
-    assert _lib.load().paced_abi_version() == 2
+    assert _lib.load().paced_abi_version() == 3
 
 
 def test_product_never_imports_the_oracle():

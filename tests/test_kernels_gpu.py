@@ -434,6 +434,106 @@ def test_enc_attention_fwd_bwd(N, S, H, p):
     assert err < 2e-2 * tl.grad.abs().max().item() + 1e-3, ("dbias", err)
 
 
+def _head_major(t, pad=0, fill=float("nan")):
+    """[rows, features] -> head-major view [features/64, rows, 64] of a buffer with `pad` unused rows after every head."""
+    R, F = t.shape
+    buf = torch.full((F // 64, R + pad, 64), fill, device=t.device, dtype=t.dtype)
+    buf[:, :R] = t.view(R, F // 64, 64).permute(1, 0, 2)
+    return buf[:, :R], buf
+
+
+@pytest.mark.parametrize("M,N,Kc,trans_b", [(40, 192, 64, False), (300, 384, 128, False), (1000, 2304, 768, False),
+                                            (1000, 768, 256, True), (4099, 1536, 192, False)])
+def test_gemm_head_major_output(M, N, Kc, trans_b):
+    """Every tile configuration writes the same bits as the row-major product, as [N/64] contiguous [M, 64] matrices."""
+    a = bf(rnd((M, Kc), 60))
+    b = bf(rnd((Kc, N) if trans_b else (N, Kc), 61))
+    want = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    K.gemm(a, b, want, trans_b=trans_b)
+    got, buf = _head_major(torch.zeros_like(want), pad=24)
+    buf.fill_(float("nan"))
+    K.gemm(a, b, got, trans_b=trans_b)
+    assert torch.equal(got.permute(1, 0, 2).reshape(M, N), want)
+    assert torch.isnan(buf[:, M:].float()).all()        # nothing written between the heads
+    with pytest.raises(ValueError):
+        K.gemm(a, b, torch.empty(N // 64, M, 32, device=DEV, dtype=torch.bfloat16), trans_b=trans_b)
+
+
+@pytest.mark.parametrize("M,N,Kc", [(40, 64, 128), (300, 256, 192), (1000, 768, 768), (4099, 768, 2304), (2500, 3072, 768)])
+@pytest.mark.parametrize("epi", ["plain", "res_drop", "dx"])
+def test_gemm_head_major_a(M, N, Kc, epi):
+    """y = x W^T (+ epilogue) and dx = dy W with the activation operand head-major: the bits of the row-major call."""
+    a = bf(rnd((M, Kc), 62))
+    ah, _ = _head_major(a, pad=8)
+    tb = epi == "dx"
+    b = bf(rnd((Kc, N) if tb else (N, Kc), 63, 0.05))
+    kw = dict(trans_b=tb)
+    if epi == "res_drop":
+        kw.update(epilogue=K.EPI_RES_DROP, aux=bf(rnd((M, N), 64)), drop_p=0.1, drop_seed=7)
+    want = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    got = torch.empty_like(want)
+    K.gemm(a, b, want, **kw)
+    K.gemm(ah, b, got, **kw)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("T,O,Iin", [(40, 64, 128), (333, 256, 192), (1000, 2304, 768), (4099, 768, 768), (70000, 768, 768)])
+@pytest.mark.parametrize("which", ["a", "b"])
+def test_gemm_weight_gradient_with_a_head_major_operand(T, O, Iin, which):
+    """dW = dy^T x (fp32 atomics) with dy (operand a) or x (operand b) head-major; ragged token counts included."""
+    dy, x = bf(rnd((T, O), 65)), bf(rnd((T, Iin), 66))
+    want = torch.zeros(O, Iin, device=DEV)
+    K.gemm(dy, x, want, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=1)
+    got = torch.zeros_like(want)
+    # (a ragged last step of the contraction reads up to 63 rows past T: they must hold finite values -- here zeros and
+    # the next head's rows -- and meet the other operand's zeros)
+    dyh, _ = _head_major(dy, pad=16, fill=0.0)
+    xh, _ = _head_major(x, pad=16, fill=0.0)
+    K.gemm(dyh if which == "a" else dy, xh if which == "b" else x, got, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=1)
+    assert torch.equal(got, want)                          # one split: no atomic reordering, so the same bits
+    got.zero_()
+    K.gemm(dyh if which == "a" else dy, xh if which == "b" else x, got, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)
+    assert (got - want).abs().max().item() <= 2e-3 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("N,S,H", [(2, 16, 2), (1, 100, 3), (2, 256, 12), (1, 333, 1)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("what", ["qkv", "all"])
+def test_enc_attention_head_major_operands_give_the_same_bits(N, S, H, p, what):
+    I, M = H * 64, N * S
+    qkv = bf(rnd((M, 3 * I), 46, 0.35))
+    tbl = _bias_table(H, S, 47)
+    dctx = bf(rnd((M, I), 48))
+    ctx0 = torch.empty(M, I, device=DEV, dtype=torch.bfloat16)
+    lse0 = torch.empty(N * H * S, device=DEV)
+    K.enc_attn_fwd(qkv[:, :I], qkv[:, I:2 * I], qkv[:, 2 * I:], ctx0, lse0, tbl, N, S, H, drop_p=p, drop_seed=5)
+    dqkv0 = torch.full((M, 3 * I), float("nan"), device=DEV, dtype=torch.bfloat16)
+    dtbl0 = torch.zeros(1, H, 2 * S - 1, device=DEV)
+    K.enc_attn_bwd(qkv[:, :I], qkv[:, I:2 * I], qkv[:, 2 * I:], ctx0, dctx, lse0, tbl, dqkv0[:, :I], dqkv0[:, I:2 * I], dqkv0[:, 2 * I:],
+                   dtbl0, N, S, H, drop_p=p, drop_seed=5)
+
+    heads, _ = _head_major(qkv, pad=8)                                   # [3H, M, 64]
+    q, k, v = heads[:H], heads[H:2 * H], heads[2 * H:]
+    lse1 = torch.empty_like(lse0)
+    dtbl1 = torch.zeros_like(dtbl0)
+    if what == "qkv":
+        ctx1 = torch.empty_like(ctx0)
+        K.enc_attn_fwd(q, k, v, ctx1, lse1, tbl, N, S, H, drop_p=p, drop_seed=5)
+        dqkv1 = torch.full_like(dqkv0, float("nan"))
+        K.enc_attn_bwd(q, k, v, ctx1, dctx, lse1, tbl, dqkv1[:, :I], dqkv1[:, I:2 * I], dqkv1[:, 2 * I:], dtbl1, N, S, H, drop_p=p, drop_seed=5)
+        got_ctx, got_dqkv = ctx1, dqkv1
+    else:
+        ctx1, _ = _head_major(torch.zeros_like(ctx0), pad=8)
+        K.enc_attn_fwd(q, k, v, ctx1, lse1, tbl, N, S, H, drop_p=p, drop_seed=5)
+        dctx1, _ = _head_major(dctx, pad=8)
+        dqkv1, buf = _head_major(torch.zeros_like(dqkv0), pad=8)
+        buf.fill_(float("nan"))
+        K.enc_attn_bwd(q, k, v, ctx1, dctx1, lse1, tbl, dqkv1[:H], dqkv1[H:2 * H], dqkv1[2 * H:], dtbl1, N, S, H, drop_p=p, drop_seed=5)
+        got_ctx, got_dqkv = ctx1.permute(1, 0, 2).reshape(M, I), dqkv1.permute(1, 0, 2).reshape(M, 3 * I)
+    assert torch.equal(got_ctx, ctx0) and torch.equal(lse1, lse0) and torch.equal(got_dqkv, dqkv0)
+    assert (dtbl0 - dtbl1).abs().max().item() <= 1e-5 * dtbl0.abs().max().item()      # order of the atomic adds
+
+
 def test_enc_attention_rescale_branch_forced():
     """One key far above the rest in a late tile forces the online-softmax running-max update."""
     N, S, H, I = 1, 192, 1, 64
