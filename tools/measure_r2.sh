@@ -33,3 +33,9 @@ cp $O/pmc_traffic.json profiles/r2_pmc_traffic.json
 cp $O/pmc_traffic_mining.json profiles/r2_pmc_traffic_mining.json
 timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err || { tail -n 20 $O/bench.err; exit 1; }
 cat $O/bench.json
+# ---- encoder attention: per-kernel durations and memory-path counters (two --pmc passes)
+bash tools/ab_attn_kernels.sh > $O/attn_kernels.txt 2>&1 || { tail -n 5 $O/attn_kernels.txt; exit 1; }
+cd $R
+bash tools/pmc_mem_attention.sh > /dev/null 2>&1 || { echo "attention counters failed"; exit 1; }
+cd $R
+cp gpurun_out/pmc_mem_attention/table.txt $O/pmc_mem_attention.txt
