@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
-"""Cycle stamps of the dQ kernel (a library built with -DDBG_STAMPS, given by PACED_HIP_LIB): where a workgroup's time goes.
-Stamp 0 / 14: 100 MHz wall clock at entry / after the last tile; 1: cycle counter at entry; per key tile kt < 4:
-2+3kt top of the tile, 3+3kt after its second barrier, 4+3kt after its first 32 keys."""
+"""Cycle stamps from inside the encoder attention's backward kernels: where a workgroup's time goes.
+
+Needs a build of csrc/attention.hip with the stamps compiled in, given by PACED_HIP_LIB:
+  WHICH=dq   (default): -DDBG_STAMPS -DDBG_STAMPS_DQ    (the dQ kernel leaves its stamps in the bias-gradient buffer)
+  WHICH=dkdv          : -DDBG_STAMPS -DDBG_STAMPS_DKDV  (the dK/dV kernel leaves them in the dQ output; the dQ kernel returns at once)
+e.g.  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-gpu-rdc -DDBG_STAMPS -DDBG_STAMPS_DQ -c pacednegatives_amd/csrc/attention.hip -o attn.o
+      hipcc --offload-arch=gfx950 -shared -fPIC pacednegatives_amd/lib/obj/{api,gemm,ops,mining}.o attn.o -o ab/libpaced_stamps.so
+Stamp 0 / 14: 100 MHz wall clock at entry / at the end; 1: cycle counter at entry.  dQ, per key tile kt < 4: 2+3kt top of
+the tile, 3+3kt after its second barrier, 4+3kt after its first 32 keys.  dK/dV: 2 top of query tile 0; per query tile
+qt < 4: 3+2qt after its second barrier, 4+2qt at its end; 11 after the last tile, 12 after the dK/dV stores, 13 after the
+bias gradient's flush."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
