@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     // p * dO = 0.
     const float kneg = key < S ? 0.f : -1e30f;
     // dropout: the 16-bit field of this lane's key inside the two hash words of an aligned key quad, as a v_perm_b32 selector
-    const uint32_t fsel = 0x0c0c0000u | ((2u * (keyc & 3) + 1u) << 8) | (2u * (keyc & 3));
+    const uint32_t dmul = paced_drop_multiplier(keyc & 3);     // this lane's key is element keyc & 3 of its hash quad
     const uint64_t S4q = (uint64_t)((S + 3) & ~3) >> 2;
     // hash quad number of (query 4*hh + (lane & 3), this lane's key quad); + 8 * S4q per register group, + 32 * S4q per tile
     uint64_t hq = (((uint64_t)n * a.H + h) * S + 4 * hh + (lane & 3)) * S4q + (keyc >> 2);
@@ -457,18 +457,17 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             // consecutive KEYS of one query.  The 4 lanes of an aligned key quad therefore need the same
             // 4 hashes: lane (l & 3) evaluates the one of query q4 + (l & 3) and a quad broadcast hands
             // each to the other three.
-            uint32_t w0 = 0, w1 = 0;
-            if (DROP) paced_drop_words(a.drop.seed, hq + (uint64_t)(8 * rg) * S4q, w0, w1);
-            uint32_t b0[4], b1[4];                     // words of queries q4 .. q4+3 (quad broadcasts of lanes 0..3)
-            b0[0] = quad_bcast<0>(w0); b0[1] = quad_bcast<1>(w0); b0[2] = quad_bcast<2>(w0); b0[3] = quad_bcast<3>(w0);
-            b1[0] = quad_bcast<0>(w1); b1[1] = quad_bcast<1>(w1); b1[2] = quad_bcast<2>(w1); b1[3] = quad_bcast<3>(w1);
+            uint32_t y = 0;
+            if (DROP) y = paced_drop_state(a.drop.seed, hq + (uint64_t)(8 * rg) * S4q);
+            uint32_t ys[4];                            // states of queries q4 .. q4+3 (quad broadcasts of lanes 0..3)
+            ys[0] = quad_bcast<0>(y); ys[1] = quad_bcast<1>(y); ys[2] = quad_bcast<2>(y); ys[3] = quad_bcast<3>(y);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * rg + e;
                 const int o = e + 8 * rg;
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, kneg));
                 float f = 1.f;
-                if (DROP) f = __builtin_amdgcn_perm(b1[e], b0[e], fsel) >= a.drop.thresh ? a.drop.scale : 0.f;
+                if (DROP) f = paced_mad24(ys[e], dmul, ys[e]) >= a.drop.limit ? a.drop.scale : 0.f;
                 pd[r] = p * f;
                 s[r] = p * (dp[r] * f - del4[o]);
             }
@@ -629,18 +628,13 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {           // registers 4rg .. 4rg+3 hold 4 consecutive keys: one hash evaluation
-                uint32_t w0 = 0, w1 = 0;
-                if (DROP) paced_drop_words(a.drop.seed, hq + (uint64_t)(kt * 16 + 8 * j + 2 * rg), w0, w1);
+                bool keep[4] = {true, true, true, true};
+                if (DROP) drop_keep4_on(a.drop, (hq + (uint64_t)(kt * 16 + 8 * j + 2 * rg)) << 2, keep);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rg + e;
                     const float pe = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, nl));
-                    float f = 1.f;
-                    if (DROP) {
-                        const uint32_t word = e < 2 ? w0 : w1;
-                        const uint32_t field = (e & 1) ? (word >> 16) : (word & 0xffffu);
-                        f = field >= a.drop.thresh ? a.drop.scale : 0.f;
-                    }
+                    const float f = !DROP ? 1.f : keep[e] ? a.drop.scale : 0.f;
                     s[r] = pe * (dp[r] * f - delta);
                 }
             }

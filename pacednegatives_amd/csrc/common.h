@@ -44,40 +44,58 @@ __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32: RNE, NaN kept
 
 // ---------------------------------------------------------------------------------------------
-// Counter-based dropout.  One hash evaluation serves FOUR neighbouring elements: element idx takes the
-// (idx & 3)-th 16-bit field of a 64-bit value derived from the quad number idx >> 2, and is KEPT when
-// its field >= thresh16 = round(p * 65536); so the realised rate is p quantised to 1/65536, and kept
-// values are scaled by 1/(1 - thresh16/65536).  Forward and backward kernels recompute the same
-// decision from the same (seed, index), so no mask is ever stored.
-__host__ __device__ __forceinline__ uint32_t paced_mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+// Counter-based dropout.  One hash state serves FOUR neighbouring elements: element idx takes the
+// (idx & 3)-th of four 32-bit values derived from the quad number idx >> 2 and is KEPT when the top
+// 16 bits of its value are >= thresh16 = round(p * 65536), i.e. when value >= thresh16 << 16; so the
+// realised rate is p quantised to 1/65536, and kept values are scaled by 1/(1 - thresh16/65536).
+// Forward and backward kernels recompute the same decision from the same (seed, index), so no mask
+// is ever stored.  Every multiply is 24 x 24 bits (v_mad_u32_u24, a full-rate instruction; a 32-bit
+// integer multiply issues at a quarter of that): two multiply / xor-shift rounds make the state, one
+// multiply-add per element makes its value.  tools/dropout_hash_stats.py holds the statistics the
+// constants were chosen by (keep rates, pair correlations at distances 1 .. 2^19 and between the four
+// values, dependence on index bits, neighbouring seeds, byte histograms).
+__host__ __device__ __forceinline__ uint32_t paced_mad24(uint32_t a, uint32_t c, uint32_t add) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, c) + add;
+#else
+    return (a & 0xffffffu) * (c & 0xffffffu) + add;
+#endif
+}
+// the state shared by the four elements of quad number `quad`
+__host__ __device__ __forceinline__ uint32_t paced_drop_state(uint32_t seed, uint64_t quad) {
+    const uint32_t hi = (uint32_t)(quad >> 32) & 0xffffffu;
+    uint32_t x = paced_mad24(hi, 0x9e3779u, (uint32_t)quad ^ seed);
+    x ^= x >> 16; x = paced_mad24(x, 0xeb352du, x);
+    x ^= x >> 13; x = paced_mad24(x, 0x2c1b3du, x);
+    x ^= x >> 12;
     return x;
 }
-// the two 32-bit words (fields 0,1 and fields 2,3) of quad number `quad`
-__host__ __device__ __forceinline__ void paced_drop_words(uint32_t seed, uint64_t quad, uint32_t& h0, uint32_t& h1) {
-    const uint32_t hi = (uint32_t)(quad >> 32) & 0xffffffu;
-    h0 = paced_mix32(((uint32_t)quad ^ seed) + hi * 0x9e3779u);     // 24 x 24-bit product: a full-rate multiply
-    h1 = (h0 ^ (h0 >> 13)) * 0xc2b2ae35u;
-    h1 ^= h1 >> 15;
+// value of element e (0..3) of a quad with state y: kept iff value >= DropCfg::limit
+template <int E> __host__ __device__ __forceinline__ uint32_t paced_drop_value(uint32_t y) {
+    constexpr uint32_t C = E == 0 ? 0x1b873bu : E == 1 ? 0x6ca68bu : E == 2 ? 0xb2ae35u : 0xd4e12du;
+    return paced_mad24(y, C, y);
 }
-__host__ __device__ __forceinline__ uint32_t paced_drop_bits(uint32_t seed, uint64_t idx) {
-    uint32_t h0, h1;
-    paced_drop_words(seed, idx >> 2, h0, h1);
-    const uint32_t h = (idx & 2) ? h1 : h0;
-    return (idx & 1) ? (h >> 16) : (h & 0xffffu);
+__host__ __device__ __forceinline__ uint32_t paced_drop_multiplier(int e) {
+    return e == 0 ? 0x1b873bu : e == 1 ? 0x6ca68bu : e == 2 ? 0xb2ae35u : 0xd4e12du;
+}
+__host__ __device__ __forceinline__ uint32_t paced_drop_bits(uint32_t seed, uint64_t idx) {   // 16-bit field of one element
+    const uint32_t y = paced_drop_state(seed, idx >> 2);
+    return paced_mad24(y, paced_drop_multiplier((int)(idx & 3)), y) >> 16;
 }
 struct DropCfg {
     uint32_t seed;
     uint32_t thresh;   // 16-bit threshold; 0 => dropout disabled
+    uint32_t limit;    // thresh << 16: an element is kept iff its 32-bit value >= limit
     float scale;       // 1/(1-p) for the quantised p
 };
 __host__ __forceinline__ DropCfg make_drop(float p, uint32_t seed) {
     DropCfg d;
     d.seed = seed;
-    if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; return d; }
+    if (p <= 0.f) { d.thresh = 0; d.limit = 0; d.scale = 1.f; return d; }
     double t = (double)p * 65536.0 + 0.5;
     d.thresh = t >= 65535.0 ? 65535u : (uint32_t)t;
     if (d.thresh == 0) d.thresh = 1;
+    d.limit = d.thresh << 16;
     d.scale = (float)(1.0 / (1.0 - (double)d.thresh / 65536.0));
     return d;
 }
@@ -85,33 +103,24 @@ __device__ __forceinline__ float drop_factor(const DropCfg& d, uint64_t idx) {
     if (d.thresh == 0) return 1.f;
     return paced_drop_bits(d.seed, idx) >= d.thresh ? d.scale : 0.f;
 }
-// factors of the aligned quad (idx4 a multiple of 4 .. idx4 + 3) from ONE hash evaluation
+// keep decisions of the aligned quad (idx4 a multiple of 4 .. idx4 + 3) from ONE state (dropout known to be on)
+__device__ __forceinline__ void drop_keep4_on(const DropCfg& d, uint64_t idx4, bool (&k)[4]) {
+    const uint32_t y = paced_drop_state(d.seed, idx4 >> 2);
+    k[0] = paced_drop_value<0>(y) >= d.limit;
+    k[1] = paced_drop_value<1>(y) >= d.limit;
+    k[2] = paced_drop_value<2>(y) >= d.limit;
+    k[3] = paced_drop_value<3>(y) >= d.limit;
+}
+// factors of the aligned quad, dropout known to be on (no uniform branch per call)
+__device__ __forceinline__ void drop_factor4_on(const DropCfg& d, uint64_t idx4, float (&f)[4]) {
+    bool k[4];
+    drop_keep4_on(d, idx4, k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = k[e] ? d.scale : 0.f;
+}
 __device__ __forceinline__ void drop_factor4(const DropCfg& d, uint64_t idx4, float (&f)[4]) {
     if (d.thresh == 0) { f[0] = f[1] = f[2] = f[3] = 1.f; return; }
-    uint32_t h0, h1;
-    paced_drop_words(d.seed, idx4 >> 2, h0, h1);
-    f[0] = (h0 & 0xffffu) >= d.thresh ? d.scale : 0.f;
-    f[1] = (h0 >> 16) >= d.thresh ? d.scale : 0.f;
-    f[2] = (h1 & 0xffffu) >= d.thresh ? d.scale : 0.f;
-    f[3] = (h1 >> 16) >= d.thresh ? d.scale : 0.f;
-}
-// same with dropout known to be on (no uniform branch per call)
-__device__ __forceinline__ void drop_factor4_on(const DropCfg& d, uint64_t idx4, float (&f)[4]) {
-    uint32_t h0, h1;
-    paced_drop_words(d.seed, idx4 >> 2, h0, h1);
-    f[0] = (h0 & 0xffffu) >= d.thresh ? d.scale : 0.f;
-    f[1] = (h0 >> 16) >= d.thresh ? d.scale : 0.f;
-    f[2] = (h1 & 0xffffu) >= d.thresh ? d.scale : 0.f;
-    f[3] = (h1 >> 16) >= d.thresh ? d.scale : 0.f;
-}
-// keep decisions only (dropout known to be on): for callers that apply the 1/(1-p) scale elsewhere
-__device__ __forceinline__ void drop_keep4_on(const DropCfg& d, uint64_t idx4, bool (&k)[4]) {
-    uint32_t h0, h1;
-    paced_drop_words(d.seed, idx4 >> 2, h0, h1);
-    k[0] = (h0 & 0xffffu) >= d.thresh;
-    k[1] = (h0 >> 16) >= d.thresh;
-    k[2] = (h1 & 0xffffu) >= d.thresh;
-    k[3] = (h1 >> 16) >= d.thresh;
+    drop_factor4_on(d, idx4, f);
 }
 // factors of 8 consecutive elements starting at a multiple of 4
 __device__ __forceinline__ void drop_factor8(const DropCfg& d, uint64_t idx4, float (&f)[8]) {

@@ -190,10 +190,19 @@ def test_forward_backward_at_real_widths(d, H, ff):
     within(f"d={d} worst per-tensor gradient L2 error", worst, 5e-2)
 
 
-def test_dropout_masks_replayed_in_the_oracle():
+@pytest.mark.parametrize("seed", [77, 83, 86])
+def test_dropout_masks_replayed_in_the_oracle(seed):
     """Dropout ON: the engine never stores a mask, forward and backward kernels recompute it from (seed, site, index).
     Rebuild every site's mask from the same seeds with the library's mask function, replay them in the oracle and
-    compare logits and all gradients: pins the seed wiring and index layout of all ten dropout sites of both stacks."""
+    compare logits and all gradients: pins the seed wiring and index layout of all ten dropout sites of both stacks.
+
+    Gradient bounds.  About one ReLU input in a thousand lies within bf16 rounding of zero, and a unit whose input rounds
+    to the other side of zero in one of the two paths switches a whole row of its weight gradient on or off (measured:
+    0.1156 of a tensor's 0.1161 error norm in one row); with six decoder rows per batch one such unit is several per
+    cent of a tensor.  Over the 20 step seeds 70..89 the largest per-tensor relative L2 error was 1.0e-2 .. 9.1e-2 (seed
+    83: a decoder unit whose change reaches every tensor below it) and the median over tensors 0.9e-2 .. 4.7e-2; the
+    seeds here are the former fixed one, the worst and the best of those.  A site wired to the wrong seed or index
+    layout puts 2p(1-p) = 18 % of its elements under the wrong factor: tens of per cent in every tensor below it."""
     from pacednegatives_amd import kernels as K
     from pacednegatives_amd import t5_engine as E
     m, P = make_model()
@@ -202,7 +211,7 @@ def test_dropout_masks_replayed_in_the_oracle():
     g = torch.Generator().manual_seed(21)
     ids = torch.randint(2, TINY.vocab_size, (B, S), generator=g)
     labels = torch.tensor([[6136, 1], [1176, 1], [6136, 1]])
-    st = m.engine.forward(ids, labels, save=True, drop_p=p, seed=77)
+    st = m.engine.forward(ids, labels, save=True, drop_p=p, seed=seed)
     assert st.cross2
     site_id = {"emb": (E._SITE_EMB, E._SITE_DEC_EMB), "final": (E._SITE_ENC_FINAL, E._SITE_DEC_FINAL), "att": E._SITE_ATT,
                "att_out": E._SITE_ATT_OUT, "ff_act": E._SITE_FF_ACT, "ff_out": E._SITE_FF_OUT, "catt": E._SITE_CATT,
@@ -212,8 +221,8 @@ def test_dropout_masks_replayed_in_the_oracle():
         sid = site_id[site]
         if isinstance(sid, tuple):             # stack-level sites have their own ids per stack and no decoder offset
             sid, dec = sid[1 if dec else 0], False
-        seed = m.engine._seed(st, sid, layer, dec)
-        mk = lambda n: K.dropout_mask(n, drop_p=p, drop_seed=seed).cpu()  # noqa: E731
+        site_seed = m.engine._seed(st, sid, layer, dec)
+        mk = lambda n: K.dropout_mask(n, drop_p=p, drop_seed=site_seed).cpu()  # noqa: E731
         if site == "att" and not dec:              # [N,H,S,S4] with key rows padded to a multiple of 4
             n, h, t, sl = shape
             s4 = (sl + 3) // 4 * 4
@@ -231,7 +240,7 @@ def test_dropout_masks_replayed_in_the_oracle():
     scale = lg.abs().max().item()
     within("dropout on: logits vs oracle replaying the masks", relerr(st.logits.cpu().view_as(lg), lg.detach()), B_LOGITS_EMU)
     # with the masks of another seed the logits differ far more than that: the comparison is not vacuous
-    st2 = m.engine.forward(ids, labels, save=False, drop_p=p, seed=78)
+    st2 = m.engine.forward(ids, labels, save=False, drop_p=p, seed=seed + 1)
     assert (st2.logits.cpu().view_as(lg) - lg.detach()).abs().max().item() > 5e-2 * scale
     loss = torch.empty(B * 2, device="cuda")
     dl = torch.empty(B * 2, TINY.vocab_size, device="cuda", dtype=torch.bfloat16)
@@ -241,10 +250,13 @@ def test_dropout_masks_replayed_in_the_oracle():
     torch.cuda.synchronize()
     got = {k: v.cpu() for k, v in m.params.to_hf("grad").items()}
     torch.nn.functional.cross_entropy(lg.view(-1, lg.shape[-1]), labels.view(-1), reduction="mean").backward()
+    errs = {}
     for k, v in leaves.items():
         want = v.grad if v.grad is not None else torch.zeros_like(v)
-        l2 = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
-        assert l2 < (8e-2 if int((want != 0).sum()) < 16 else 5e-2), (k, l2)
+        errs[k] = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
+    worst = max(errs, key=errs.get)
+    within(f"dropout on, seed {seed}: worst per-tensor gradient L2 error ({worst})", errs[worst], 1.2e-1)
+    within(f"dropout on, seed {seed}: median per-tensor gradient L2 error", sorted(errs.values())[len(errs) // 2], 6e-2)
 
 
 def test_cross_attention_paths_agree():

@@ -359,6 +359,23 @@ def test_rmsnorm_bwd_with_output_dropout_and_second_output(M, d):
     np.testing.assert_allclose(dw.cpu().numpy(), wf.grad.cpu().numpy(), rtol=2e-3, atol=2e-3 * wf.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("p,seed", [(0.1, 5), (0.5, 0xdeadbeef), (0.013, 123456789)])
+def test_dropout_mask_equals_the_numpy_restatement(p, seed):
+    """The device's keep decisions against the numpy restatement of the same counter-based function (the one whose
+    statistics tools/dropout_hash_stats.py reports), element for element, and the realised rate against p."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from dropout_hash_stats import drop_values
+    n = 1 << 20
+    got = K.dropout_mask(n, drop_p=p, drop_seed=seed).cpu().numpy()
+    thresh = int(p * 65536 + 0.5)
+    keep = (drop_values(seed, np.arange(n, dtype=np.uint64)) >> np.uint64(16)) >= np.uint64(thresh)
+    scale = np.float32(1.0 / (1.0 - thresh / 65536.0))
+    assert np.array_equal(got, np.where(keep, scale, np.float32(0)))
+    assert abs(keep.mean() - (1 - p)) < 4 * math.sqrt(p * (1 - p) / n)
+
+
 def test_embedding_fwd_bwd():
     V, d, M = 1000, 128, 777
     table = bf(rnd((V, d), 30))
