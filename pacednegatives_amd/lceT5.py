@@ -172,16 +172,50 @@ class FusedAdamW:
         self.t = 0
         self.param_groups = [{"lr": lr}]
 
+        self._early = None     # [lo, hi) ranges already updated (and their gradients cleared) in the step under way
+        self._cleared = False
+
     def zero_grad(self):
+        if self._cleared:          # a step made of range updates cleared every range as it went
+            self._cleared = False
+            return
         self.g32.zero_()
 
-    def step(self, grad_scale: float = 1.0):
-        self.t += 1
+    def _update(self, lo, hi, grad_scale):
         b1, b2 = self.betas
         lr = self.param_groups[0]["lr"]
         step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
-        K.adamw(self.p32, self.g32, self.m, self.v, self.p16, beta1=b1, beta2=b2, eps=self.eps, step_size=step_size,
-                decay=lr * self.weight_decay, grad_scale=grad_scale)
+        p16 = self.p16[lo:hi] if self.p16 is not None else None
+        K.adamw(self.p32[lo:hi], self.g32[lo:hi], self.m[lo:hi], self.v[lo:hi], p16, beta1=b1, beta2=b2, eps=self.eps,
+                step_size=step_size, decay=lr * self.weight_decay, grad_scale=grad_scale)
+
+    def step_range(self, lo: int, hi: int, grad_scale: float = 1.0):
+        """Update elements [lo, hi) now, on the current stream, and clear their gradients: for callers that know the
+        range's gradients are final before the rest of the backward pass has run.  The following ``step()`` takes
+        the elements no ``step_range`` of the same step covered; ranges must be disjoint."""
+        if self._early is None:
+            self.t += 1
+            self._early = []
+        self._update(lo, hi, grad_scale)
+        self.g32[lo:hi].zero_()
+        self._early.append((lo, hi))
+
+    def step(self, grad_scale: float = 1.0):
+        if self._early is None:
+            self.t += 1
+            self._update(0, self.p32.numel(), grad_scale)
+            return
+        at = 0
+        for lo, hi in sorted(self._early) + [(self.p32.numel(), self.p32.numel())]:
+            if lo < at:
+                raise RuntimeError("step_range calls of one step overlap")
+            if lo > at:
+                self._update(at, lo, grad_scale)
+                self.g32[at:lo].zero_()
+            at = hi
+        self._early = None
+        self._cleared = True
+
 
 
 class LinearWarmupSchedule:
@@ -233,6 +267,8 @@ class LCEModel:
         self.share_forward = bool(self.hparams.get("share_forward", False))
         # run the no-grad forwards of a step on a second stream beside the forwards that keep state
         self.overlap_forwards = bool(self.hparams.get("overlap_forwards", os.environ.get("PACED_OVERLAP_FORWARDS", "1") != "0"))
+        # with overlap_forwards on one rank: AdamW of a segment as soon as its gradients are final (see training_step)
+        self.early_update = bool(self.hparams.get("early_update", os.environ.get("PACED_EARLY_UPDATE", "1") != "0"))
         self._side_stream = self._aux_stream = None
         self.difficulty = float(self.weights.eta.item())
         self.global_step = 0
@@ -348,7 +384,7 @@ class LCEModel:
             meta_scheduler.step()
             return w, st_
 
-        def main_backward(after_encoder=None):
+        def main_backward(after_encoder=None, on_segments_done=None):
             """(d) forwards with state, loss, backward                                      :149-155"""
             states, plog, nlog = self._forward_pair(p, n, save=True, call=1, after_encoder=after_encoder)
             pce2 = torch.empty(2 * B, dtype=F32, device=self.device)
@@ -358,14 +394,14 @@ class LCEModel:
                 K.cross_entropy(plog, plab, pce2, dl[:2 * B], ignore_index=ign, gscale=g_pos)
                 K.cross_entropy(nlog, nlab, nce2, dl[2 * B:], ignore_index=ign, gscale=g_neg)
                 states[0].logits = None
-                self.model.engine.backward(states[0], dl)
+                self.model.engine.backward(states[0], dl, on_segments_done=on_segments_done)
             else:
                 dlp = torch.empty(plog.shape, dtype=BF16, device=self.device)
                 K.cross_entropy(plog, plab, pce2, dlp, ignore_index=ign, gscale=g_pos)
                 self.model.engine.backward(states[0], dlp)
                 dln = torch.empty(nlog.shape, dtype=BF16, device=self.device)
                 K.cross_entropy(nlog, nlab, nce2, dln, ignore_index=ign, gscale=g_neg)
-                self.model.engine.backward(states[1], dln)
+                self.model.engine.backward(states[1], dln, on_segments_done=on_segments_done)   # the last pass over the gradients
             rows = torch.empty(2 * B, dtype=F32, device=self.device)
             K.lce_group(pce2, nce2, rows, nneg, use_mean)
             return rows
@@ -391,8 +427,24 @@ class LCEModel:
                 aux.wait_stream(main)                   # parameters of the last update, and (d)'s encoder forward
                 with torch.cuda.stream(aux):
                     box["loss"] = no_grad_rows()
+                    box["no_grad_done"] = aux.record_event()
             self.model.engine.dw_stream = self._side_stream
-            main_loss = main_backward(after_encoder=start_no_grad_forwards)
+            early = None
+            if self.early_update and world == 1 and self.on_gradients_ready is None:
+                # One rank: a segment's gradients are final when its part of the backward pass is over, so its AdamW
+                # update (HBM-bound, 1.5 ms for the whole model when left to the end of the step) runs on the weight-
+                # gradient stream under the rest of the backward pass.  It waits for the chain up to here (gradient
+                # pieces the chain writes itself, and its last read of these weights) and for the no-grad forwards,
+                # which read every weight.  With more ranks the all-reduce of the whole buffer comes first.
+                P, side = self.model.params, self._side_stream
+
+                def early(first, last):
+                    lo, hi = P.span(first, last)
+                    side.wait_stream(main)
+                    side.wait_event(box["no_grad_done"])
+                    with torch.cuda.stream(side):
+                        opt.step_range(lo, hi)
+            main_loss = main_backward(after_encoder=start_no_grad_forwards, on_segments_done=early)
             main.wait_stream(aux)
             loss = box["loss"]
             loss.record_stream(main)

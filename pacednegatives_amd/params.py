@@ -104,6 +104,15 @@ class ParamStore:
     def grad(self, name):
         return self._view(self.g32, name)
 
+    def span(self, first: str, last: str) -> Tuple[int, int]:
+        """[lo, hi) of the flat buffers covering segments ``first`` .. ``last`` (layout order), padding included."""
+        keys = list(self.layout)
+        lo = self.layout[first][0]
+        hi = self.layout[keys[keys.index(last) + 1]][0]
+        if hi <= lo:
+            raise ValueError(f"{first!r} does not precede {last!r} in the layout")
+        return lo, hi
+
     def names(self) -> Iterator[str]:
         return (k for k in self.layout if k != "__total__")
 

@@ -334,9 +334,14 @@ class T5Engine:
         return st
 
     # ------------------------------------------------------------------ backward
-    def backward(self, st: ForwardState, dlogits: torch.Tensor) -> None:
+    def backward(self, st: ForwardState, dlogits: torch.Tensor, on_segments_done=None) -> None:
         """Accumulate parameter gradients of one forward call into ``params.g32`` given d loss / d logits
-        (bf16 [N*2, V]).  The forward must have been run with ``save=True``."""
+        (bf16 [N*2, V]).  The forward must have been run with ``save=True``.
+
+        ``on_segments_done(first, last)``, if given, is called when every kernel that writes the gradients of the
+        layout segments first .. last, or reads their weights, has been enqueued (on the calling stream and on
+        ``dw_stream``): once after the decoder stack (all of its segments) and once after each encoder layer.  The
+        tied embedding, the encoder's relative bias and its final norm are complete only when backward() returns."""
         dims, P = self.dims, self.params
         if not st.enc_layers or st.g_last is None:
             raise RuntimeError("backward needs a forward state produced with save=True")
@@ -442,6 +447,8 @@ class T5Engine:
             dg = dg0
             sv.__dict__.clear()            # release this layer's activations
         K.embedding_bwd(st.dec_ids, dg, P.grad("shared"), drop_p=p, drop_seed=self._seed(st, _SITE_DEC_EMB))
+        if on_segments_done is not None:
+            on_segments_done("dec.0.ln1", "dec.final_ln")
         if st.cross2:
             # d enc[n] = sum over layers and projected queries of ds (x) qk + dropout(p) (x) dz: one token-contraction product
             Kc = nd * 4 * H
@@ -497,6 +504,8 @@ class T5Engine:
                           drop2_p=p if need2 else 0.0, drop2_seed=self._seed(st, _SITE_FF_OUT, l - 1) if need2 else 0)
             dh = dh_in
             sv.__dict__.clear()
+            if on_segments_done is not None:
+                on_segments_done(pre + "ln1", pre + "wo")
         K.embedding_bwd(st.ids, dh, P.grad("shared"), drop_p=p, drop_seed=self._seed(st, _SITE_EMB))
         K.relbias_table_bwd(dbias_tbl, st.bucket_enc, P.grad("enc.rel_bias"))
         if self.dw_stream is not None:

@@ -373,7 +373,7 @@ def test_side_stream_forwards_give_the_same_steps(neg_len):
     atomics, so later steps agree to rounding, not bit for bit."""
     from pacednegatives_amd.lceT5 import LCEModel
     from pacednegatives_amd.synthetic import token_batch
-    runs = []
+    runs, moved = [], []
     for overlap in (False, True):
         hp = {"model_name": "t5-tiny", "total_steps": 10, "eta": 0.9, "batch_size": 4, "lr": 1e-3, "meta_lr": 1e-2, "n": 3,
               "warmup_steps": 0, "use_mean": False, "ignore_index": -100, "dropout": 0.1, "dropout_seed": 5,
@@ -382,6 +382,7 @@ def test_side_stream_forwards_give_the_same_steps(neg_len):
             warnings.simplefilter("ignore")
             model = LCEModel(hp)
         model.model.params.load_hf(init_params(RTINY, 0))
+        start = model.model.params.p32.clone().cpu()
         assert model.overlap_forwards is overlap
         steps = []
         for it in range(4):
@@ -391,13 +392,20 @@ def test_side_stream_forwards_give_the_same_steps(neg_len):
             out = model.training_step((pos, neg), it)
             steps.append((out["loss_rows"].cpu(), out["main_loss_rows"].cpu(), out["weights"].cpu(), model.difficulty))
         assert (model._side_stream is not None) is overlap
+        assert model.early_update and model.model.params.g32.abs().max().item() == 0      # every range cleared, however it was updated
         runs.append(steps)
+        moved.append((model.model.params.p32 - start.to("cuda")).cpu())
     for it, (a, b) in enumerate(zip(*runs)):
         if it == 0:
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         for x, y in zip(a[:3], b[:3]):
             np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=2e-3, atol=1e-5)
         assert abs(a[3] - b[3]) < 1e-5
+    # the overlapped schedule updates the decoder and each encoder layer as soon as its gradients are final, on the
+    # weight-gradient stream; the four steps must move every parameter as the in-order schedule's single update does
+    within("parameter change over 4 steps, overlapped vs in-order schedule (relative L2)",
+           ((moved[0] - moved[1]).norm() / moved[0].norm()).item(), 2e-2)
+    assert moved[0].norm().item() > 0
 
 
 def test_share_forward_gives_the_steps_of_the_two_pass_schedule():
