@@ -200,19 +200,28 @@ class FusedAdamW:
         self.g32[lo:hi].zero_()
         self._early.append((lo, hi))
 
+    def pending_ranges(self):
+        """[lo, hi) ranges the next ``step()`` will update: everything, or what the step's ``step_range`` calls left."""
+        n = self.p32.numel()
+        if self._early is None:
+            return [(0, n)]
+        out, at = [], 0
+        for lo, hi in sorted(self._early) + [(n, n)]:
+            if lo < at:
+                raise RuntimeError("step_range calls of one step overlap")
+            if lo > at:
+                out.append((at, lo))
+            at = hi
+        return out
+
     def step(self, grad_scale: float = 1.0):
         if self._early is None:
             self.t += 1
             self._update(0, self.p32.numel(), grad_scale)
             return
-        at = 0
-        for lo, hi in sorted(self._early) + [(self.p32.numel(), self.p32.numel())]:
-            if lo < at:
-                raise RuntimeError("step_range calls of one step overlap")
-            if lo > at:
-                self._update(at, lo, grad_scale)
-                self.g32[at:lo].zero_()
-            at = hi
+        for lo, hi in self.pending_ranges():
+            self._update(lo, hi, grad_scale)
+            self.g32[lo:hi].zero_()
         self._early = None
         self._cleared = True
 
@@ -430,27 +439,36 @@ class LCEModel:
                     box["no_grad_done"] = aux.record_event()
             self.model.engine.dw_stream = self._side_stream
             early = None
-            if self.early_update and world == 1 and self.on_gradients_ready is None:
-                # One rank: a segment's gradients are final when its part of the backward pass is over, so its AdamW
-                # update (HBM-bound, 1.5 ms for the whole model when left to the end of the step) runs on the weight-
-                # gradient stream under the rest of the backward pass.  It waits for the chain up to here (gradient
-                # pieces the chain writes itself, and its last read of these weights) and for the no-grad forwards,
-                # which read every weight.  With more ranks the all-reduce of the whole buffer comes first.
+            if self.early_update and self.on_gradients_ready is None:
+                # A segment's gradients are final when its part of the backward pass is over.  Its exchange over the
+                # ranks and its AdamW update (HBM-bound, 1.5 ms for the whole model when left to the end of the step)
+                # then run under the rest of the backward pass: the decoder's segments in one piece, each encoder layer
+                # as it completes.  One rank: on the weight-gradient stream.  Several ranks: on the stream of the no-grad
+                # forwards, which has nothing else left to do, so that an all-reduce never sits in front of a weight-
+                # gradient product.  Either way the update waits for the chain up to here (gradient pieces the chain
+                # writes itself, and its last read of these weights), for the segment's weight-gradient products and
+                # for the no-grad forwards, which read every weight.  A communication kernel holding 16-64 compute units
+                # for 5 ms of the backward pass costs the step 0.0-0.7 ms (tools/cu_holder_step.py).
                 P, side = self.model.params, self._side_stream
+                lane = side if world == 1 else aux
 
                 def early(first, last):
                     lo, hi = P.span(first, last)
-                    side.wait_stream(main)
-                    side.wait_event(box["no_grad_done"])
-                    with torch.cuda.stream(side):
-                        opt.step_range(lo, hi)
+                    lane.wait_stream(main)
+                    if lane is not side:
+                        lane.wait_stream(side)
+                    lane.wait_event(box["no_grad_done"])
+                    with torch.cuda.stream(lane):
+                        parallel.allreduce_sum_(P.g32[lo:hi])
+                        opt.step_range(lo, hi, grad_scale=1.0 / world)
             main_loss = main_backward(after_encoder=start_no_grad_forwards, on_segments_done=early)
             main.wait_stream(aux)
             loss = box["loss"]
             loss.record_stream(main)
             weights, stats = meta_update(loss)
         # main update                                                                        :156-157
-        parallel.allreduce_sum_(self.model.params.g32)          # one all-reduce over the flat fp32 gradient buffer
+        for lo, hi in opt.pending_ranges():                     # the whole flat fp32 buffer, or what no early update took
+            parallel.allreduce_sum_(self.model.params.g32[lo:hi])
         if self.on_gradients_ready is not None:                 # tests: the summed gradients, before the update clears them
             self.on_gradients_ready(self)
         opt.step(grad_scale=1.0 / world)

@@ -1,10 +1,12 @@
 """Data-parallel helpers: one process per GPU, collectives through ``torch.distributed`` (backend
 "nccl" is RCCL over xGMI on ROCm; "gloo" on CPU for tests).
 
-The lceT5 step has exactly two exchange points per step (what Lightning's DDP strategy does for the
-reference, ``train/train_lce.py:89-91``): the 1-float gradient of eta after the meta backward, and the
-parameter gradients after the main backward.  Both are summed here and divided by the world size
-inside the AdamW kernel (``grad_scale``), so each is ONE all-reduce over a contiguous fp32 buffer.
+The lceT5 step exchanges what Lightning's DDP strategy exchanges for the reference
+(``train/train_lce.py:89-91``): the 1-float gradient of eta after the meta backward, and the parameter
+gradients of the main backward.  Both are summed here and divided by the world size inside the AdamW
+kernel (``grad_scale``).  The parameter gradients live in one contiguous fp32 buffer: the first step
+exchanges it in ONE all-reduce after the backward pass, later steps in contiguous ranges as their
+gradients become final (``LCEModel.training_step``).
 """
 from __future__ import annotations
 

@@ -33,10 +33,14 @@ def main(out_dir):
         warnings.simplefilter("ignore")
         model = LCEModel(hp)
     grads = []
-    model.on_gradients_ready = lambda m: grads.append((m.model.params.g32 / world).cpu().numpy().copy())
+    # PACED_TEST_EARLY=1: no look at the summed gradients, so that from the second step on each segment is exchanged
+    # and updated as soon as its gradients are final, under the rest of the backward pass
+    early = os.environ.get("PACED_TEST_EARLY") == "1"
+    if not early:
+        model.on_gradients_ready = lambda m: grads.append((m.model.params.g32 / world).cpu().numpy().copy())
     out = {}
     b = B // world
-    for it in range(2):
+    for it in range(3 if early else 2):
         pos, neg = token_batch(B, NNEG, S, dims.vocab_size, seed=50 + it)
         sl, nsl = slice(rank * b, (rank + 1) * b), slice(rank * b * NNEG, (rank + 1) * b * NNEG)
         batch = ({k: v[sl] for k, v in pos.items()}, {k: v[nsl] for k, v in neg.items()})
@@ -45,7 +49,9 @@ def main(out_dir):
         out[f"main_rows{it}"] = res["main_loss_rows"].cpu().numpy()
         out[f"weights{it}"] = res["weights"].cpu().numpy()
         out[f"eta{it}"] = np.array([model.difficulty])
-        out[f"grad{it}"] = grads[-1]
+        if not early:
+            out[f"grad{it}"] = grads[-1]
+    assert model.model.params.g32.abs().max().item() == 0, "gradients not cleared after the update"
     out["p32"] = model.model.params.p32.cpu().numpy()
 
     # sharded pool selection: integer-valued embeddings (exact scores, many ties), rows split over the ranks

@@ -25,13 +25,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_world(world, out_dir):
+def _run_world(world, out_dir, **extra_env):
     os.makedirs(out_dir, exist_ok=True)
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), PACED_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), PACED_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
         procs.append(subprocess.Popen([sys.executable, "-X", "faulthandler", WORKER, out_dir], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -75,6 +75,28 @@ def test_two_rank_step_equals_one_rank_on_the_whole_batch(runs):
     # flips sign between the two summation orders differ by up to 2 lr per step; they must be rare
     diff = np.abs(two[0]["p32"] - one["p32"])
     assert diff.max() <= 4.2e-3 and (diff > 1e-4).mean() < 0.02, (diff.max(), (diff > 1e-4).mean())
+
+
+def test_segment_wise_exchange_and_update_equals_one_rank(tmp_path):
+    """From the second step on, the decoder's segments and each encoder layer are all-reduced and updated as soon as
+    their gradients are final, on a side stream under the rest of the backward pass, and only the remainder (tied
+    embedding, encoder bias table and final norm) after it.  Three steps of two ranks on halves of the batch against one
+    rank on the whole batch (which takes the same early updates without an exchange), and against the schedule that
+    exchanges and updates everything at the end of the step."""
+    one = _run_world(1, str(tmp_path / "w1"), PACED_TEST_EARLY="1")[0]
+    two = _run_world(2, str(tmp_path / "w2"), PACED_TEST_EARLY="1")
+    late = _run_world(2, str(tmp_path / "w2late"), PACED_TEST_EARLY="1", PACED_EARLY_UPDATE="0")
+    for it in range(3):
+        for key in ("rows", "main_rows", "weights"):
+            got = np.concatenate([two[r][f"{key}{it}"] for r in range(2)])
+            np.testing.assert_allclose(got, one[f"{key}{it}"], rtol=2e-3, atol=1e-6, err_msg=f"{key}{it}")
+            np.testing.assert_allclose(got, np.concatenate([late[r][f"{key}{it}"] for r in range(2)]), rtol=2e-3, atol=1e-6)
+        assert two[0][f"eta{it}"] == two[1][f"eta{it}"]
+        np.testing.assert_allclose(two[0][f"eta{it}"], one[f"eta{it}"], rtol=1e-5)
+    assert np.array_equal(two[0]["p32"], two[1]["p32"]), "ranks hold different parameters after three updates"
+    for other in (one["p32"], late[0]["p32"]):
+        diff = np.abs(two[0]["p32"] - other)           # see the note on AdamW's first steps above
+        assert diff.max() <= 6.3e-3 and (diff > 1e-4).mean() < 0.03, (diff.max(), (diff > 1e-4).mean())
 
 
 def test_sharded_pool_selection_equals_unsharded_bit_for_bit(runs):
