@@ -306,6 +306,12 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ["PACED_HANG_DUMP"]), exit=True)
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))         # this process never touches the GPU
+    # stdout carries the JSON line and nothing else: libraries write notices there (RCCL prints the path of its
+    # shared object when the first communicator is made, gloo its connections), so file descriptor 1 points at
+    # stderr until the line is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     from pacednegatives_amd.trainer import init_distributed
     rank, world, local = init_distributed()
     if world != args.gpus:
@@ -321,8 +327,11 @@ def main():
         out["secondary"] = run_mining(args, rank, world, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, dims)
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out))
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -450,7 +450,7 @@ class LCEModel:
                 # for the no-grad forwards, which read every weight.  A communication kernel holding 16-64 compute units
                 # for 5 ms of the backward pass costs the step 0.0-0.7 ms (tools/cu_holder_step.py).
                 P, side = self.model.params, self._side_stream
-                lane = side if world == 1 else aux
+                lane = side if world == 1 and not parallel.exchange_forced() else aux
 
                 def early(first, last):
                     lo, hi = P.span(first, last)

@@ -34,10 +34,18 @@ def _host_staged(d) -> bool:
     return d.get_backend() != "nccl"
 
 
+def exchange_forced() -> bool:
+    """PACED_FORCE_EXCHANGE=1: a process group of ONE rank still issues every all-reduce, and the step takes the
+    schedule of several ranks.  A rehearsal of the RCCL call sites (stream order, ranges of the gradient buffer as
+    collective operands) on a single GPU; the sums are those of one rank."""
+    import os
+    return os.environ.get("PACED_FORCE_EXCHANGE") == "1" and _dist() is not None
+
+
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks (no-op for a single process)."""
     d = _dist()
-    if d and d.get_world_size() > 1:
+    if d and (d.get_world_size() > 1 or exchange_forced()):
         if t.is_cuda and _host_staged(d):
             host = t.detach().cpu()              # also orders the exchange after the kernels that produced t
             d.all_reduce(host, op=d.ReduceOp.SUM)

@@ -45,7 +45,8 @@ def init_distributed():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         local %= max(1, torch.cuda.device_count())
-    if world > 1 and not dist.is_initialized():
+    rehearsal = os.environ.get("PACED_FORCE_EXCHANGE") == "1"        # one rank that still exchanges: see parallel.exchange_forced
+    if (world > 1 or rehearsal) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("PACED_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
