@@ -93,6 +93,13 @@ int paced_gemm_set_tile(int tile);
  * Process-wide; meant for benchmarking and tests. */
 int paced_gemm_set_ring(int on);
 
+/* Upper limit on the workgroups of a 256x256 phased launch: 0 = one per compute unit (default; PACED_GEMM_GRID=n sets
+ * a limit at load).  A phased workgroup keeps its compute unit for the whole launch, so the units a smaller grid leaves
+ * out are where kernels of other streams can start meanwhile: LCEModel.training_step sets a limit around the no-grad
+ * forwards (lceT5.py:131-133) that run beside the two-token decoder of the pass that keeps state.  Process-wide, read
+ * at launch time on the calling thread. */
+int paced_gemm_set_grid(int workgroups);
+
 /* Which kernel the calling process's most recent paced_gemm_bf16[_batched] launch used: the tile edge (64, 128 or 256;
  * 256 is the phased kernel), plus 1 when the ring variant took it; 0 before the first launch.  For profilers that
  * attribute launch times to kernels (bench.py's roofline leg). */

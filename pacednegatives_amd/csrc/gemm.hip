@@ -894,6 +894,8 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
 namespace {
 
 int g_force_tile = 0;    // 0 = heuristic, 128 or 256 = forced (paced_gemm_set_tile, for benchmarking)
+int g_grid_limit = 0;    // 0 = one phased workgroup per CU; n > 0: at most n (paced_gemm_set_grid; PACED_GEMM_GRID at load)
+bool g_grid_env_read = false;
 
 int cu_count() {
     static int cached[64] = {0};
@@ -937,9 +939,12 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     const int ktiles = (p.K + BK - 1) / BK;
     constexpr bool PHASED = std::is_same<Cfg, CfgPhased>::value;
     int slots = cu_count() * (PHASED ? 1 : std::is_same<Cfg, CfgTiny>::value ? 6 : 3);     // workgroups resident per CU
-    if (PHASED) {        // PACED_GEMM_GRID=n: at most n workgroups (diagnostic: how the rate scales with the CUs in use)
-        static const int limit = [] { const char* e = getenv("PACED_GEMM_GRID"); return e ? atoi(e) : 0; }();
-        if (limit > 0 && limit < slots) slots = limit;
+    if (PHASED) {
+        // At most g_grid_limit workgroups: the compute units the grid leaves out stay free for the kernels of other
+        // streams for as long as this launch runs (a phased workgroup holds all of a unit's LDS and registers until
+        // the whole launch is over, so nothing else starts on a unit it has taken).
+        if (!g_grid_env_read) { const char* e = getenv("PACED_GEMM_GRID"); if (e && g_grid_limit == 0) g_grid_limit = atoi(e); g_grid_env_read = true; }
+        if (g_grid_limit > 0 && g_grid_limit < slots) slots = g_grid_limit;
     }
     constexpr bool RINGABLE = !PHASED && EPI != EPI_TOPK_DENSE && EPI != EPI_TOPK_FILTER;
     const bool ring_on = ring_enabled();
@@ -1047,6 +1052,13 @@ extern "C" int paced_gemm_set_tile(int tile) {
 }
 
 extern "C" int paced_gemm_last_kernel(void) { return g_last_kernel; }
+
+extern "C" int paced_gemm_set_grid(int workgroups) {
+    PACED_CHECK_ARG(workgroups >= 0, "paced_gemm_set_grid: the limit must be >= 0 (0 = one workgroup per compute unit)");
+    g_grid_limit = workgroups;
+    g_grid_env_read = true;
+    return PACED_OK;
+}
 
 extern "C" int paced_gemm_set_ring(int on) {
     g_ring = on ? 1 : 0;

@@ -121,6 +121,11 @@ def gemm_set_ring(on: bool):
     _lib.check(_lib.load().paced_gemm_set_ring(int(bool(on))), "paced_gemm_set_ring")
 
 
+def gemm_set_grid(workgroups: int):
+    """At most that many workgroups per 256x256 phased launch from now on (0 = one per compute unit)."""
+    _lib.check(_lib.load().paced_gemm_set_grid(int(workgroups)), "paced_gemm_set_grid")
+
+
 def gemm_set_tile(tile: int):
     """0 = heuristic, 128 or 256 = force that tile configuration (benchmarks and tests)."""
     _lib.check(_lib.load().paced_gemm_set_tile(tile), "paced_gemm_set_tile")

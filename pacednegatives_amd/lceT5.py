@@ -278,7 +278,13 @@ class LCEModel:
         self.overlap_forwards = bool(self.hparams.get("overlap_forwards", os.environ.get("PACED_OVERLAP_FORWARDS", "1") != "0"))
         # with overlap_forwards on one rank: AdamW of a segment as soon as its gradients are final (see training_step)
         self.early_update = bool(self.hparams.get("early_update", os.environ.get("PACED_EARLY_UPDATE", "1") != "0"))
+        # with overlap_forwards: the no-grad forwards' 256x256 products leave compute units to the decoder (see training_step)
+        # (default: 7 of every 8 compute units; 0 = no limit)
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        self.nograd_grid = int(self.hparams.get("nograd_grid", os.environ.get("PACED_NOGRAD_GRID", str(cus * 7 // 8))))
+        self.nograd_grid_layers = int(self.hparams.get("nograd_grid_layers", os.environ.get("PACED_NOGRAD_GRID_LAYERS", "1000")))
         self._side_stream = self._aux_stream = None
+        self._host_vals = None                 # pinned: what a step hands to the host (statistics, eta, mean main loss)
         self.difficulty = float(self.weights.eta.item())
         self.global_step = 0
         self.logged = OrderedDict()
@@ -393,26 +399,32 @@ class LCEModel:
             meta_scheduler.step()
             return w, st_
 
-        def main_backward(after_encoder=None, on_segments_done=None):
-            """(d) forwards with state, loss, backward                                      :149-155"""
+        def main_backward(after_encoder=None, on_segments_done=None, on_rows=None):
+            """(d) forwards with state, loss, backward                                      :149-155
+            ``on_rows(rows)`` runs once the LCE rows are enqueued, before the backward pass is."""
             states, plog, nlog = self._forward_pair(p, n, save=True, call=1, after_encoder=after_encoder)
             pce2 = torch.empty(2 * B, dtype=F32, device=self.device)
             nce2 = torch.empty(2 * B * nneg, dtype=F32, device=self.device)
+            rows = torch.empty(2 * B, dtype=F32, device=self.device)
             if len(states) == 1:
                 dl = torch.empty(states[0].logits.shape, dtype=BF16, device=self.device)
                 K.cross_entropy(plog, plab, pce2, dl[:2 * B], ignore_index=ign, gscale=g_pos)
                 K.cross_entropy(nlog, nlab, nce2, dl[2 * B:], ignore_index=ign, gscale=g_neg)
+                K.lce_group(pce2, nce2, rows, nneg, use_mean)
+                if on_rows is not None:
+                    on_rows(rows)
                 states[0].logits = None
                 self.model.engine.backward(states[0], dl, on_segments_done=on_segments_done)
             else:
                 dlp = torch.empty(plog.shape, dtype=BF16, device=self.device)
                 K.cross_entropy(plog, plab, pce2, dlp, ignore_index=ign, gscale=g_pos)
-                self.model.engine.backward(states[0], dlp)
                 dln = torch.empty(nlog.shape, dtype=BF16, device=self.device)
                 K.cross_entropy(nlog, nlab, nce2, dln, ignore_index=ign, gscale=g_neg)
+                K.lce_group(pce2, nce2, rows, nneg, use_mean)
+                if on_rows is not None:
+                    on_rows(rows)
+                self.model.engine.backward(states[0], dlp)
                 self.model.engine.backward(states[1], dln, on_segments_done=on_segments_done)   # the last pass over the gradients
-            rows = torch.empty(2 * B, dtype=F32, device=self.device)
-            K.lce_group(pce2, nce2, rows, nneg, use_mean)
             return rows
 
         if share:
@@ -432,11 +444,34 @@ class LCEModel:
                 self._aux_stream = torch.cuda.Stream(device=self.device)
             aux, box = self._aux_stream, {}
 
+            if self._host_vals is None:
+                self._host_vals = torch.zeros(8, dtype=F32).pin_memory()
+
             def start_no_grad_forwards():
                 aux.wait_stream(main)                   # parameters of the last update, and (d)'s encoder forward
-                with torch.cuda.stream(aux):
-                    box["loss"] = no_grad_rows()
-                    box["no_grad_done"] = aux.record_event()
+                eng = self.model.engine
+                if self.nograd_grid > 0:
+                    eng.on_encoder_layer = lambda l: K.gemm_set_grid(self.nograd_grid if l < self.nograd_grid_layers else 0)
+                try:
+                    with torch.cuda.stream(aux):
+                        box["loss"] = no_grad_rows()
+                        box["no_grad_done"] = aux.record_event()
+                        # (b) follows (a) on the same stream, as in the reference.  What the host reads of it (the
+                        # statistics, eta after the update) is final here, long before the backward pass is over: the
+                        # copy to pinned memory is enqueued now and only its event is waited for at the end of the step,
+                        # so the host enqueues the next step while the GPU is still in this one's backward pass.
+                        box["weights"], box["stats"] = meta_update(box["loss"])
+                        self._host_vals[0:4].copy_(box["stats"], non_blocking=True)
+                        self._host_vals[4:5].copy_(self.weights.eta, non_blocking=True)
+                        box["meta_read"] = aux.record_event()
+                finally:
+                    eng.on_encoder_layer = None
+                    if self.nograd_grid > 0:
+                        K.gemm_set_grid(0)
+
+            def read_main_loss(rows):
+                self._host_vals[5:6].copy_(rows.mean().view(1), non_blocking=True)
+                box["main_read"] = main.record_event()
             self.model.engine.dw_stream = self._side_stream
             early = None
             if self.early_update and self.on_gradients_ready is None:
@@ -461,11 +496,11 @@ class LCEModel:
                     with torch.cuda.stream(lane):
                         parallel.allreduce_sum_(P.g32[lo:hi])
                         opt.step_range(lo, hi, grad_scale=1.0 / world)
-            main_loss = main_backward(after_encoder=start_no_grad_forwards, on_segments_done=early)
+            main_loss = main_backward(after_encoder=start_no_grad_forwards, on_segments_done=early, on_rows=read_main_loss)
             main.wait_stream(aux)
-            loss = box["loss"]
-            loss.record_stream(main)
-            weights, stats = meta_update(loss)
+            loss, weights, stats = box["loss"], box["weights"], box["stats"]
+            for t in (loss, weights, stats):
+                t.record_stream(main)
         # main update                                                                        :156-157
         for lo, hi in opt.pending_ranges():                     # the whole flat fp32 buffer, or what no early update took
             parallel.allreduce_sum_(self.model.params.g32[lo:hi])
@@ -476,7 +511,12 @@ class LCEModel:
         opt.zero_grad()
 
         # one host read-back per step: stats of (b), eta after the meta update, mean main loss
-        host = torch.cat([stats, self.weights.eta, main_loss.mean().view(1)]).tolist()
+        if overlap and not share:
+            box["meta_read"].synchronize()
+            box["main_read"].synchronize()
+            host = self._host_vals[0:6].tolist()
+        else:
+            host = torch.cat([stats, self.weights.eta, main_loss.mean().view(1)]).tolist()
         avg_weight, meta_loss_mean, _deta, loss_mean, eta, main_mean = host
         self.log("avg_weight", avg_weight)
         self.log("meta_loss", meta_loss_mean)

@@ -131,6 +131,7 @@ class T5Engine:
         self._bucket_cache: Dict[int, torch.Tensor] = {}
         self.force_kv_projection = False      # tests: take the explicit K/V projection path of the cross-attention
         self.dw_stream = None                  # when set: weight-gradient products of backward() run on this stream
+        self.on_encoder_layer = None           # when set: called with the layer index before each encoder layer of forward() is enqueued
         self.ffn_bit_mask = os.environ.get("PACED_FFN_BITMASK", "1") != "0"   # encoder FFN backward masks by saved sign bits
         self.head_major = os.environ.get("PACED_HEAD_MAJOR", "1") != "0"   # encoder attention operands head-major (see forward)
         self._bucket_dec = torch.tensor([0, 1], dtype=torch.int32, device=self.device)   # offsets 0 and -1 (HF:244-249)
@@ -230,6 +231,8 @@ class T5Engine:
         for l in range(dims.num_layers):
             pre = f"enc.{l}."
             sv = _EncLayerSaved()
+            if self.on_encoder_layer is not None:
+                self.on_encoder_layer(l)
             xn, rstd1 = self._empty(M, d), torch.empty(M, dtype=F32, device=self.device)
             K.rmsnorm_fwd(h, P.w(pre + "ln1"), xn, rstd1, eps=dims.eps)
             # The attention's operands are head-major ([heads, M, 64]; the products write and read that layout): a
