@@ -512,6 +512,12 @@ class LCEModel:
 
         # one host read-back per step: stats of (b), eta after the meta update, mean main loss
         if overlap and not share:
+            # The host goes on to enqueue the next step as soon as these two copies have landed.  Its allocations then
+            # meet blocks of this step that other streams have not released yet (the backward's operands, handed to the
+            # weight-gradient stream), so two steps' activations can be alive at once: where that does not fit the
+            # GPU's memory the allocator would stall and re-allocate every step, and the host waits for the whole step.
+            if 2 * torch.cuda.max_memory_allocated(self.device) > 0.85 * torch.cuda.get_device_properties(self.device).total_memory:
+                main.synchronize()
             box["meta_read"].synchronize()
             box["main_read"].synchronize()
             host = self._host_vals[0:6].tolist()
