@@ -99,6 +99,32 @@ def test_gemm_many_tiles_per_workgroup_exact(ta, tb, tile):
         assert torch.equal(c2, want)
 
 
+@pytest.mark.parametrize("limit", [1, 100, 224])
+def test_gemm_grid_limit_gives_the_same_product(limit):
+    """paced_gemm_set_grid: a phased launch with fewer workgroups than compute units walks more items per workgroup
+    and leaves the other units free; the product is the same, ragged tiles and split contraction included."""
+    M, N, Kc = 5000, 4104, 192
+    a, b = ints((M, Kc), -2, 2, 31), ints((N, Kc), -2, 2, 32)
+    A, B = bf(a), bf(b)
+    want = A.float() @ B.float().t()
+    K.gemm_set_tile(256)
+    try:
+        K.gemm_set_grid(limit)
+        c = torch.full((M, N), float("nan"), device=DEV)
+        K.gemm(A, B, c, epilogue=K.EPI_F32)
+        assert K._lib.load().paced_gemm_last_kernel() == 256
+        g = torch.zeros(Kc, Kc, device=DEV)                      # weight-gradient shape: the split follows the limit
+        K.gemm(A[:, :Kc], A[:, :Kc], g, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0)
+        torch.cuda.synchronize()
+    finally:
+        K.gemm_set_grid(0)
+        K.gemm_set_tile(0)
+    assert torch.equal(c, want)
+    assert torch.equal(g, A.float().t() @ A.float())
+    with pytest.raises(RuntimeError):
+        K.gemm_set_grid(-1)
+
+
 def test_gemm_batched_per_head_products(tile):
     """The three batched shapes of the decoder cross-attention: per-head slices of a projection matrix."""
     R, H, dk, d = 72, 3, 64, 192                       # rows (sequences x 2), heads, head size, model width
