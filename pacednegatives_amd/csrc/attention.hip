@@ -352,13 +352,11 @@ template <bool DROP>
 __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PAD = 32;        // table entries in front of index 0: query rows past S (last tile) index below it
-    char* lQr = smem;              // 32 x 64 row image of Q
-    char* lQt = smem + 4096;       // tr image of Q
-    char* lDr = smem + 8192;       // row image of dO
-    char* lDt = smem + 12288;      // tr image of dO
-    float* llse = reinterpret_cast<float*>(smem + 16384);     // 32
-    float* ldel = llse + 32;                                  // 32
-    float* lbias = ldel + 32;                                 // PAD + 2S + 160
+    // A query tile's staging area: row and tr images of Q and dO (4 x 4 KB: 32 x 64 each), then its 32 LSE and 32 delta
+    // values.  Two of them: tile t+1 is staged while tile t is being consumed, so a tile costs ONE barrier (with a single
+    // area it costs two: one before the area is overwritten and one after).
+    constexpr int STG = 16384 + 256;
+    float* lbias = reinterpret_cast<float*>(smem + 2 * STG);  // PAD + 2S + 160
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5;
     const int n = blockIdx.z, h = blockIdx.y, bx = blockIdx.x, S = a.S;
     const int LB = 2 * S + 160;
@@ -408,34 +406,42 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     const int ntile = (S + 31) / 32;
     // bias entry of (this lane's key, query 4*hh of the tile): register r reads lb[-(8*(r>>2) + (r&3))]
     const float* lb = lbias + (PAD + keyc + S - 1 - 4 * hh);
-    const float* lse4 = llse + 4 * hh;
-    const float* del4 = ldel + 4 * hh;
+    // the staged registers (one 16-byte chunk of Q, dO and O per thread, the row's LSE) into a staging area
+    auto stage = [&](char* area) {
+        *reinterpret_cast<bf16x8*>(area + row_img_off(sr, sc)) = qv;
+        *reinterpret_cast<bf16x8*>(area + 4096 + tr_img_off(sr, sc)) = qv;
+        *reinterpret_cast<bf16x8*>(area + 8192 + row_img_off(sr, sc)) = dv;
+        *reinterpret_cast<bf16x8*>(area + 12288 + tr_img_off(sr, sc)) = dv;
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += bf2f(dv[j]) * bf2f(ov[j]);       // delta = rowsum(dO * O)
+        d += lane_xor1(d); d += lane_xor2(d); d += lane_mirror8(d);       // sum over the row's 8 threads
+        if (sc == 0) {
+            float* f = reinterpret_cast<float*>(area + 16384);
+            f[sr] = lsev;
+            f[32 + sr] = d;
+        }
+    };
+    auto fetch = [&](int qt) {
+        const int qrow = qt * 32 + sr;
+        qv = bload8(rQ, (qrow * a.ld + sc * 8) * 2);
+        dv = bload8(rD, (qrow * a.lddo + sc * 8) * 2);
+        ov = bload8(rO, (qrow * a.ldo + sc * 8) * 2);
+        lsev = bloadf(rL, qrow);
+    };
+    stage(smem);
+    if (1 < ntile) fetch(1);
+    __syncthreads();                 // tile 0, the bias table and the zeroed bias-gradient sums are in LDS
     for (int qt = 0; qt < ntile; ++qt, lb -= 32, hq += 32 * S4q) {
         if (qt == 0) STAMP(2);
-        __syncthreads();
-        {   // stage Q and dO tiles and delta = rowsum(dO * O)
-            *reinterpret_cast<bf16x8*>(lQr + row_img_off(sr, sc)) = qv;
-            *reinterpret_cast<bf16x8*>(lQt + tr_img_off(sr, sc)) = qv;
-            *reinterpret_cast<bf16x8*>(lDr + row_img_off(sr, sc)) = dv;
-            *reinterpret_cast<bf16x8*>(lDt + tr_img_off(sr, sc)) = dv;
-            float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d += bf2f(dv[j]) * bf2f(ov[j]);
-            d += lane_xor1(d); d += lane_xor2(d); d += lane_mirror8(d);       // sum over the row's 8 threads
-            if (sc == 0) {
-                ldel[sr] = d;
-                llse[sr] = lsev;
-            }
-        }
-        __syncthreads();
+        const char* cur = smem + (qt & 1) * STG;
+        const char* lQr = cur;              // 32 x 64 row image of Q
+        const char* lQt = cur + 4096;       // tr image of Q
+        const char* lDr = cur + 8192;       // row image of dO
+        const char* lDt = cur + 12288;      // tr image of dO
+        const float* lse4 = reinterpret_cast<const float*>(cur + 16384) + 4 * hh;
+        const float* del4 = lse4 + 32;
         if (qt < 4) STAMP(3 + 2 * qt);
-        if (qt + 1 < ntile) {
-            const int qrow = (qt + 1) * 32 + sr;
-            qv = bload8(rQ, (qrow * a.ld + sc * 8) * 2);
-            dv = bload8(rD, (qrow * a.lddo + sc * 8) * 2);
-            ov = bload8(rO, (qrow * a.ldo + sc * 8) * 2);
-            lsev = bloadf(rL, qrow);
-        }
 
         f32x16 s, dp;
 #pragma unroll
@@ -495,6 +501,11 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lQt, 16 * s2, 0, lane), df, dk0, 0, 0, 0);
             dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(lQt, 16 * s2, 1, lane), df, dk1, 0, 0, 0);
         }
+        if (qt + 1 < ntile) {          // the next tile's registers arrived under this tile's arithmetic
+            stage(smem + ((qt + 1) & 1) * STG);
+            if (qt + 2 < ntile) fetch(qt + 2);
+        }
+        __syncthreads();               // next tile visible; everyone is done with the area the tile after it overwrites
         if (qt < 4) STAMP(4 + 2 * qt);
     }
     STAMP(11);
@@ -1225,7 +1236,16 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
     a.lse = const_cast<float*>(lse); a.bias = bias_tbl; a.dbias = dbias_tbl; a.dbias_replicas = dbias_replicas;
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const dim3 grid((S + 127) / 128, H, N);
-    const size_t smem1 = 16384 + (size_t)(64 + 32 + 2 * (2 * S + 160)) * 4;
+    const size_t smem1 = 2 * (16384 + 256) + (size_t)(32 + 2 * (2 * S + 160)) * 4;      // two staging areas, bias table, bias-gradient sums
+    if (smem1 > 65536) {      // sequences beyond ~1900 tokens
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (16384 + 256) + (32 + 2 * (2 * 2048 + 160)) * 4);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (16384 + 256) + (32 + 2 * (2 * 2048 + 160)) * 4);
+            if (e != hipSuccess) { paced_set_error("paced_enc_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PACED_ERR_HIP; }
+            attr_set = true;
+        }
+    }
     if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<true>), grid, dim3(256), smem1, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<false>), grid, dim3(256), smem1, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
