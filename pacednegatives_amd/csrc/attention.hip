@@ -360,7 +360,13 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, hh = lane >> 5;
     const int n = blockIdx.z, h = blockIdx.y, bx = blockIdx.x, S = a.S;
     const int LB = 2 * S + 160;
-    float* ldb = lbias + PAD + LB;                            // 2S + 160
+    // Bias-gradient sums.  A (wave, lane half) writes every diagonal of the table at most once over its sweep (lane j of
+    // tile qt owns diagonal j - 32 qt + const), so with one array per wave and half the sums are stored with plain LDS
+    // writes and added up at the end: `priv` (S <= 512: 8 arrays fit beside two workgroups' staging areas).  Longer
+    // sequences share ONE array through LDS atomics; an LDS float atomic costs ~1000 cycles per tile of this loop (a
+    // quarter of the kernel at 256 tokens), which is why the private arrays exist.
+    const bool priv = S <= 512;
+    float* ldb = lbias + PAD + LB;                            // (priv ? 8 : 1) x (2S + 160)
     const int key = bx * 128 + w * 32 + (lane & 31);
     const int keyc = min(key, S - 1);
     const size_t rowbase = (size_t)n * S;
@@ -387,7 +393,8 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     bf16x8 ov = bload8(rO, (sr * a.ldo + sc * 8) * 2);
     float lsev = bloadf(rL, sr);
     stage_bias(floats_rsrc(a.bias ? a.bias + (size_t)h * (2 * S - 1) : nullptr, 2 * S - 1), lbias, PAD, PAD + LB);
-    for (int i = threadIdx.x; i < LB; i += 256) ldb[i] = 0.f;
+    for (int i = threadIdx.x; i < (priv ? 8 * LB : LB); i += 256) ldb[i] = 0.f;
+    float* ldb_own = ldb + (priv ? (2 * w + hh) * LB : 0);
     f32x16 dk0, dk1, dv0, dv1, zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; zero16[r] = 0.f; }
@@ -490,7 +497,10 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             diag_step<10>(s, j, all, wrapped);  diag_step<11>(s, j, all, wrapped);  diag_step<12>(s, j, all, wrapped);
             diag_step<13>(s, j, all, wrapped);  diag_step<14>(s, j, all, wrapped);  diag_step<15>(s, j, all, wrapped);
             const int idx = (bx * 128 + w * 32 + j) - qt * 32 + S - 1 - 4 * hh;      // diagonal of lane j
-            if (idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], (all - wrapped) + carry);
+            if (idx >= 0 && idx < 2 * S - 1) {
+                if (priv) ldb_own[idx] = (all - wrapped) + carry;
+                else atomicAdd(&ldb[idx], (all - wrapped) + carry);
+            }
             carry = wrapped;
         }
 #pragma unroll
@@ -529,10 +539,17 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     STAMP(12);
     if (a.dbias) {
         const int idx = (bx * 128 + w * 32 + (lane & 31)) - ntile * 32 + S - 1 - 4 * hh;   // wrapped part of the last tile
-        if (idx >= 0 && idx < 2 * S - 1) atomicAdd(&ldb[idx], carry);
+        if (idx >= 0 && idx < 2 * S - 1) {
+            if (priv) ldb_own[idx] = carry;
+            else atomicAdd(&ldb[idx], carry);
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * S - 1; i += 256) {
-            const float v = ldb[i];
+            float v = ldb[i];
+            if (priv) {
+#pragma unroll
+                for (int c = 1; c < 8; ++c) v += ldb[c * LB + i];
+            }
             // every workgroup of a head adds to the same 2S-1 words; replicas keep same-address atomics apart
             const int rep = (blockIdx.z * gridDim.x + blockIdx.x) % a.dbias_replicas;
             if (v != 0.f) atomicAdd(a.dbias + ((size_t)rep * a.H + h) * (2 * S - 1) + i, v);
@@ -1236,12 +1253,13 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
     a.lse = const_cast<float*>(lse); a.bias = bias_tbl; a.dbias = dbias_tbl; a.dbias_replicas = dbias_replicas;
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const dim3 grid((S + 127) / 128, H, N);
-    const size_t smem1 = 2 * (16384 + 256) + (size_t)(32 + 2 * (2 * S + 160)) * 4;      // two staging areas, bias table, bias-gradient sums
-    if (smem1 > 65536) {      // sequences beyond ~1900 tokens
+    // two staging areas, the bias table, the bias-gradient sums (8 arrays up to 512 tokens, one beyond)
+    const size_t smem1 = 2 * (16384 + 256) + (size_t)(32 + (1 + (S <= 512 ? 8 : 1)) * (2 * S + 160)) * 4;
+    if (smem1 > 65536) {      // 300 to 512 tokens (eight arrays of sums), or beyond ~1900
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (16384 + 256) + (32 + 2 * (2 * 2048 + 160)) * 4);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (16384 + 256) + (32 + 2 * (2 * 2048 + 160)) * 4);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
             if (e != hipSuccess) { paced_set_error("paced_enc_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PACED_ERR_HIP; }
             attr_set = true;
         }

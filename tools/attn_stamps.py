@@ -30,7 +30,8 @@ q, k, v = qkv[:, :I], qkv[:, I:2 * I], qkv[:, 2 * I:]
 p = float(os.environ.get("P", 0.1))
 K.enc_attn_fwd(q, k, v, ctx, lse, tbl, N, S, H, drop_p=p, drop_seed=1)
 for _ in range(3):
-    K.enc_attn_bwd(q, k, v, ctx, dctx, lse, tbl, dqkv[:, :I], dqkv[:, I:2 * I], dqkv[:, 2 * I:], dtbl, N, S, H, drop_p=p, drop_seed=1)
+    K.enc_attn_bwd(q, k, v, ctx, dctx, lse, tbl, dqkv[:, :I], dqkv[:, I:2 * I], dqkv[:, 2 * I:],
+                   None if os.environ.get("NODBIAS") else dtbl, N, S, H, drop_p=p, drop_seed=1)       # NODBIAS=1: without the table gradient
 torch.cuda.synchronize()
 nb = 2 * H * N
 which = os.environ.get("WHICH", "dq")
