@@ -283,6 +283,8 @@ class LCEModel:
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         self.nograd_grid = int(self.hparams.get("nograd_grid", os.environ.get("PACED_NOGRAD_GRID", str(cus * 7 // 8))))
         self.nograd_grid_layers = int(self.hparams.get("nograd_grid_layers", os.environ.get("PACED_NOGRAD_GRID_LAYERS", "1000")))
+        # with overlap_forwards: training_step returns once the numbers it logs are on the host (see there); False = wait for the step
+        self.run_ahead = bool(self.hparams.get("run_ahead", os.environ.get("PACED_RUN_AHEAD", "1") != "0"))
         self._side_stream = self._aux_stream = None
         self._host_vals = None                 # pinned: what a step hands to the host (statistics, eta, mean main loss)
         self.difficulty = float(self.weights.eta.item())
@@ -516,7 +518,8 @@ class LCEModel:
             # meet blocks of this step that other streams have not released yet (the backward's operands, handed to the
             # weight-gradient stream), so two steps' activations can be alive at once: where that does not fit the
             # GPU's memory the allocator would stall and re-allocate every step, and the host waits for the whole step.
-            if 2 * torch.cuda.max_memory_allocated(self.device) > 0.85 * torch.cuda.get_device_properties(self.device).total_memory:
+            if (not self.run_ahead or
+                    2 * torch.cuda.max_memory_allocated(self.device) > 0.85 * torch.cuda.get_device_properties(self.device).total_memory):
                 main.synchronize()
             box["meta_read"].synchronize()
             box["main_read"].synchronize()
