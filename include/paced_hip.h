@@ -100,6 +100,16 @@ int paced_gemm_set_ring(int on);
  * at launch time on the calling thread. */
 int paced_gemm_set_grid(int workgroups);
 
+/* Size in bytes of a TILE-ORDERED bit matrix for an M x N product, or 0 when a product of that shape would not take the
+ * 256x256 phased kernel (then only the row-major form, ldaux >= N/8, is accepted).  The sign-bit matrix that epilogue 2
+ * writes and epilogue 6 reads (the ReLU mask between T5DenseActDense's wi and wo, HF modeling_t5.py:288-300, kept for
+ * the backward pass reached from lceT5.py:155) is only ever passed from one launch to the other, so the two may agree on
+ * any order: with ldaux = -1 the aux buffer (16-byte aligned, at least this many bytes) holds 16 bytes per thread and
+ * 256x256 tile, in the order the kernel's threads meet the elements.  The writer then stores one 16-byte value per
+ * thread and tile instead of 16 single bytes, and the reader asks for its 16 bytes before the tile's contraction loop,
+ * so that the epilogue does not wait on memory.  Writer and reader must have the same M and N. */
+long long paced_gemm_tile_bits_bytes(int M, int N);
+
 /* Which kernel the calling process's most recent paced_gemm_bf16[_batched] launch used: the tile edge (64, 128 or 256;
  * 256 is the phased kernel), plus 1 when the ring variant took it; 0 before the first launch.  For profilers that
  * attribute launch times to kernels (bench.py's roofline leg). */

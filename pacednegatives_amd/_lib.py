@@ -26,6 +26,7 @@ SIGNATURES = {
     "paced_gemm_set_ring": (_i, [_i]),
     "paced_gemm_set_grid": (_i, [_i]),
     "paced_gemm_last_kernel": (_i, []),
+    "paced_gemm_tile_bits_bytes": (_ll, [_i, _i]),
     "paced_rmsnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _u32, _vp]),
     "paced_rmsnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u32, _f, _u32, _vp]),
     "paced_embedding_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _u32, _vp]),

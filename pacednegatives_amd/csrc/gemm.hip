@@ -617,10 +617,14 @@ __device__ __forceinline__ void wait_hidden_batch(T (&x)[8]) {
     asm volatile("s_waitcnt vmcnt(0) ; hidden-load wait" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) :: "memory");
 }
 
-template <int EPI, bool FULL>
+template <int EPI, bool FULL, bool TILED>
 __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb, int m0, int n0, int wr, int wc, int lane,
-                                                   f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
-    constexpr bool LOADS = (EPI == EPI_RES_DROP || EPI == EPI_MASK || EPI == EPI_MASK_BITS);
+                                                   f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3,
+                                                   u32x4& tbits, unsigned char* tile_bits) {
+    // TILED: the bit matrix is kept in tile order, 16 bytes per lane and tile (byte n = the lane's piece n), at tile_bits;
+    // a reader's 16 bytes arrive in tbits (requested before the tile's K loop), a writer collects them there.
+    constexpr bool LOADS = (EPI == EPI_RES_DROP || EPI == EPI_MASK || (EPI == EPI_MASK_BITS && !TILED));
+    if (TILED && EPI == EPI_RELU_DROP) tbits = u32x4{0u, 0u, 0u, 0u};
     const int rr = lane >> 3, c = lane & 7;
     const int ncol = n0 + wc * 64 + c * 8;
     const bool col_ok = FULL || ncol < p.N;           // N is a multiple of 8 on this path
@@ -694,16 +698,18 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = bf2f(aux[n & 7][e]) > 0.f ? t[e] : (bf16)0.f;
         } else if (EPI == EPI_MASK_BITS) {
+            const uint32_t byte = TILED ? tbits[n >> 2] >> ((n & 3) * 8) : mbits[n & 7];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = ((mbits[n & 7] >> e) & 1u) ? t[e] : (bf16)0.f;
+            for (int e = 0; e < 8; ++e) t[e] = ((byte >> e) & 1u) ? t[e] : (bf16)0.f;
         }
         const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
         const bool ok = FULL || (m < p.M && col_ok);
-        if (EPI == EPI_RELU_DROP && p.aux && ok) {
+        if (EPI == EPI_RELU_DROP && p.aux && (TILED || ok)) {
             unsigned int byte = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) byte |= (bf2f(t[e]) > 0.f ? 1u : 0u) << e;
-            const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (ncol >> 3)] = (unsigned char)byte;
+            if (TILED) tbits[n >> 2] |= byte << ((n & 3) * 8);
+            else const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (ncol >> 3)] = (unsigned char)byte;
         }
         if (EPI == EPI_BF16 && p.c_heads) {        // a wave's 64 columns are one head: rows of 128 bytes, 128 bytes apart
             if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)(ncol >> 6) * p.c_heads + (size_t)m * 64 + (ncol & 63)) = t;
@@ -734,13 +740,19 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
         finish(i, 0, t0);
         finish(i, 1, t1);
     }
+    if (TILED && EPI == EPI_RELU_DROP) *reinterpret_cast<u32x4*>(tile_bits) = tbits;
 }
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, void* Cb, int m0, int n0, int wr, int wc, int lane,
-                                              f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3) {
-    if (m0 + 256 <= p.M && n0 + 256 <= p.N) epilogue_rows_impl<EPI, true>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3);
-    else epilogue_rows_impl<EPI, false>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3);
+                                              f32x4 (&acc)[8][4], char* pc0, char* pc1, char* pc2, char* pc3,
+                                              u32x4& tbits, unsigned char* tile_bits) {
+    const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N;
+    if ((EPI == EPI_RELU_DROP || EPI == EPI_MASK_BITS) && tile_bits) {
+        if (full) epilogue_rows_impl<EPI, true, true>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3, tbits, tile_bits);
+        else epilogue_rows_impl<EPI, false, true>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3, tbits, tile_bits);
+    } else if (full) epilogue_rows_impl<EPI, true, false>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3, tbits, tile_bits);
+    else epilogue_rows_impl<EPI, false, false>(p, Cb, m0, n0, wr, wc, lane, acc, pc0, pc1, pc2, pc3, tbits, tile_bits);
 }
 
 template <bool TA, bool TB, int EPI>
@@ -799,6 +811,16 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A tile-ordered bit matrix (ldaux < 0): this lane's 16 bytes of the tile at ((tile * 512 + thread) * 16.  The mask
+        // is requested here, ahead of the tile's whole K loop, by a load the compiler cannot see (see epilogue_rows_impl);
+        // it is older than every operand load of the loop, whose counted waits therefore cover it from the second K step on.
+        u32x4 tbits = {0u, 0u, 0u, 0u};
+        unsigned char* tile_bits = nullptr;
+        if ((EPI == EPI_RELU_DROP || EPI == EPI_MASK_BITS) && p.aux && p.ldaux < 0) {
+            tile_bits = const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux)) +
+                        ((size_t)((m0 >> 8) * ntn + (n0 >> 8)) * 512 + tid) * 16;
+            if (EPI == EPI_MASK_BITS) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tbits) : "v"(tile_bits) : "memory");
+        }
         for (int t = 0; t < nsteps; ++t) {
             const int sB0 = base, sA0 = ring_wrap(base + 1), sB1 = ring_wrap(base + 2), sA1 = ring_wrap(base + 3);
             const int d1 = ring_wrap(base + 8), d2 = ring_wrap(base + 9);      // phases 3 and 4 reuse sB0 and sA0
@@ -866,7 +888,9 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
         if (EPI == EPI_BF16 || EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP || EPI == EPI_MASK || EPI == EPI_MASK_BITS) {
             char* s1 = sw + ring_wrap(base + 8) * HALF;      // the finished K step's B half 1 and A half 1 slots
             char* s2 = sw + ring_wrap(base + 9) * HALF;
-            epilogue_rows<EPI>(p, batch_c<EPI>(p, bz), m0, n0, wr, wc, lane, acc, s1, s1 + 8192, s2, s2 + 8192);
+            // (the host refuses a tile-ordered mask with fewer than two K steps, so the loop's waits have covered the load)
+            if (EPI == EPI_MASK_BITS) asm volatile("; tile mask bits arrived" : "+v"(tbits) :: "memory");
+            epilogue_rows<EPI>(p, batch_c<EPI>(p, bz), m0, n0, wr, wc, lane, acc, s1, s1 + 8192, s2, s2 + 8192, tbits, tile_bits);
         } else {
             epilogue<CfgPhased, EPI>(p, batch_c<EPI>(p, bz), m0, n0, wr, wc, lane, acc);
         }
@@ -1018,6 +1042,10 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
                         (p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                          (!(EPI == EPI_RES_DROP || EPI == EPI_MASK) || (p.ldaux % 8 == 0 && ((uintptr_t)p.aux & 15) == 0)));
     if (large && rows16) return launch_cfg<CfgPhased, TA, TB, EPI>(p, splits, stream);
+    if ((EPI == EPI_RELU_DROP || EPI == EPI_MASK_BITS) && p.aux && p.ldaux < 0) {
+        paced_set_error("paced_gemm_bf16: a tile-ordered bit matrix (ldaux = -1) needs a shape that takes the 256x256 kernel; ask paced_gemm_tile_bits_bytes first");
+        return PACED_ERR_ARG;
+    }
     // fewer 128x128 tiles than CUs and no K split to make up for it: quarter-size tiles
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     // (with the ring kernel half a grid of 128x128 tiles beats more than two 64x64 tiles per CU: half the operand traffic)
@@ -1052,6 +1080,13 @@ extern "C" int paced_gemm_set_tile(int tile) {
 }
 
 extern "C" int paced_gemm_last_kernel(void) { return g_last_kernel; }
+
+extern "C" long long paced_gemm_tile_bits_bytes(int M, int N) {
+    if (M < 256 || N < 256 || N % 8 != 0 || g_force_tile == 128 || g_force_tile == 64) return 0;
+    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    if (g_force_tile != 256 && t256 < 200) return 0;
+    return t256 * 8192;
+}
 
 extern "C" int paced_gemm_set_grid(int workgroups) {
     PACED_CHECK_ARG(workgroups >= 0, "paced_gemm_set_grid: the limit must be >= 0 (0 = one workgroup per compute unit)");
@@ -1113,7 +1148,8 @@ static int gemm_entry(const void* A, const void* B, void* C, const void* aux,
     if (epilogue == EPI_RES_DROP || epilogue == EPI_MASK)
         PACED_CHECK_ARG(aux && ldaux % 4 == 0 && ((uintptr_t)aux & 7) == 0, "paced_gemm_bf16: epilogue %d needs an 8-byte aligned aux with ldaux%%4==0", epilogue);
     if (epilogue == EPI_MASK_BITS || (epilogue == EPI_RELU_DROP && aux))
-        PACED_CHECK_ARG(aux && N % 8 == 0 && ldaux >= N / 8, "paced_gemm_bf16: the bit matrix needs N %% 8 == 0 and ldaux >= N/8 bytes per row");
+        PACED_CHECK_ARG(aux && N % 8 == 0 && (ldaux >= N / 8 || (ldaux == -1 && batch == 1 && ((uintptr_t)aux & 15) == 0 && K >= 2 * BK)),
+                        "paced_gemm_bf16: the bit matrix needs N %% 8 == 0 and ldaux >= N/8 bytes per row, or ldaux = -1 (tile order, 16-byte aligned, K >= 128)");
     PACED_CHECK_ARG(splits >= 0, "paced_gemm_bf16: splits must be >= 0 (0 = choose automatically)");
     PACED_CHECK_ARG(splits <= 1 || epilogue == EPI_ATOMIC_F32, "paced_gemm_bf16: split contraction needs the atomic epilogue");
     if (epilogue != EPI_ATOMIC_F32) splits = 1;

@@ -6,6 +6,8 @@ not match what its grid assumes.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -58,7 +60,8 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
 
     aux is the bf16 residual / mask operand of EPI_RES_DROP / EPI_MASK, or a uint8 [M, N/8] bit matrix
     (bit n%8 of byte n//8 of row m <-> element (m, n)): written by EPI_RELU_DROP with the sign of its
-    output, read by EPI_MASK_BITS.  a, c and a transposed b may be head-major 3-D tensors (see _operand).
+    output, read by EPI_MASK_BITS; a 1-D uint8 aux is a tile-ordered bit matrix from sign_bits_buffer.
+    a, c and a transposed b may be head-major 3-D tensors (see _operand).
     """
     lib = _lib.load()
     bits = epilogue in (EPI_RELU_DROP, EPI_MASK_BITS)
@@ -73,7 +76,12 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
     if (bf_ if trans_b else br) != N or (br if trans_b else bf_) != K:
         raise ValueError(f"b {tuple(b.shape)} does not give N={N}, K={K} (trans_b={trans_b})")
     ldaux = 0
-    if aux is not None:
+    if aux is not None and bits and aux.dim() == 1:
+        need = lib.paced_gemm_tile_bits_bytes(M, N)
+        if need == 0 or aux.numel() < need or not aux.is_contiguous():
+            raise ValueError(f"a tile-ordered bit matrix for [{M}, {N}] needs {need} contiguous bytes (0 = shape not eligible), got {aux.numel()}")
+        ldaux = -1
+    elif aux is not None:
         if bits and (N % 8 or tuple(aux.shape) != (M, N // 8)):
             raise ValueError(f"the bit matrix must be [M, N/8] = [{M}, {N}/8], got {tuple(aux.shape)}")
         if not bits and tuple(aux.shape) != (M, N):
@@ -95,6 +103,15 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
         e1.record()
         prof.append(((int(trans_a), int(trans_b), int(epilogue), lib.paced_gemm_last_kernel()), 2.0 * M * N * K, e0, e1))
     return c
+
+
+def sign_bits_buffer(M, N, device):
+    """Buffer for the sign bits EPI_RELU_DROP writes and EPI_MASK_BITS reads for an [M, N] output: 1-D (tile order) when
+    the product takes the 256x256 kernel, else the row-major [M, N/8] matrix (PACED_TILE_BITS=0: always row-major)."""
+    need = _lib.load().paced_gemm_tile_bits_bytes(M, N)
+    if need and os.environ.get("PACED_TILE_BITS", "1") != "0":
+        return torch.empty(need, dtype=torch.uint8, device=device)
+    return torch.empty(M, N // 8, dtype=torch.uint8, device=device)
 
 
 def gemm_batched(a, b, c, *, M, N, K, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, trans_a=False, trans_b=False,

@@ -252,7 +252,7 @@ class T5Engine:
             K.rmsnorm_fwd(h_mid, P.w(pre + "ln2"), xn2, rstd2, eps=dims.eps)
             act = self._empty(M, ff)
             # the backward only needs to know which activations survived relu and dropout: one bit each
-            actbits = torch.empty(M, ff // 8, dtype=torch.uint8, device=self.device) if save and self.ffn_bit_mask and ff % 8 == 0 else None
+            actbits = K.sign_bits_buffer(M, ff, self.device) if save and self.ffn_bit_mask and ff % 8 == 0 else None
             K.gemm(xn2, P.w(pre + "wi"), act, epilogue=K.EPI_RELU_DROP, aux=actbits, drop_p=p, drop_seed=self._seed(st, _SITE_FF_ACT, l))
             h_out = self._empty(M, d)
             K.gemm(act, P.w(pre + "wo"), h_out, epilogue=K.EPI_RES_DROP, aux=h_mid, drop_p=p, drop_seed=self._seed(st, _SITE_FF_OUT, l))

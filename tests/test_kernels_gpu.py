@@ -230,6 +230,50 @@ def test_gemm_sign_bit_matrix(shape, p, tile):
     assert torch.equal(by_bits.float().cpu(), want.to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("shape", [(512, 512, 128), (700, 776, 192), (4352, 3072, 128)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_gemm_tile_ordered_sign_bits(shape, p):
+    """The 256x256 kernel's own order for the sign bits (a 1-D buffer, ldaux = -1): the writer's outputs and the
+    reader's masked product equal those of the row-major bit matrix and of the mask by the saved output, on whole and
+    ragged tiles, with two and more K steps on the reader's side; shapes that do not take that kernel are refused."""
+    M, N, Kc = shape
+    lib = K._lib.load()
+    assert lib.paced_gemm_tile_bits_bytes(128, 3072) == 0 and lib.paced_gemm_tile_bits_bytes(M, 260) == 0
+    a, b = ints((M, Kc), -2, 2, 50), ints((N, Kc), -2, 2, 51)
+    g, w = ints((M, Kc), -2, 2, 52), ints((N, Kc), -2, 2, 53)
+    act, plain = torch.empty(M, N, device=DEV, dtype=torch.bfloat16), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    by_tiles, by_rows, by_act = torch.empty_like(act), torch.empty_like(act), torch.empty_like(act)
+    rows = torch.empty(M, N // 8, device=DEV, dtype=torch.uint8)
+    K.gemm_set_tile(256)
+    try:
+        need = lib.paced_gemm_tile_bits_bytes(M, N)
+        assert need == ((M + 255) // 256) * ((N + 255) // 256) * 8192
+        tiles = torch.full((need + 16,), 0xA5, device=DEV, dtype=torch.uint8)
+        K.gemm(bf(a), bf(b), act, epilogue=K.EPI_RELU_DROP, aux=tiles[:need], drop_p=p, drop_seed=77)
+        K.gemm(bf(a), bf(b), plain, epilogue=K.EPI_RELU_DROP, aux=rows, drop_p=p, drop_seed=77)
+        assert lib.paced_gemm_last_kernel() == 256
+        assert torch.equal(act, plain)
+        assert (tiles[need:] == 0xA5).all()
+        assert int(tiles[:need].view(torch.int32).ne(0).sum()) > 0
+        K.gemm(bf(g), bf(w), by_tiles, epilogue=K.EPI_MASK_BITS, aux=tiles[:need], mask_scale=1.5)
+        K.gemm(bf(g), bf(w), by_rows, epilogue=K.EPI_MASK_BITS, aux=rows, mask_scale=1.5)
+        K.gemm(bf(g), bf(w), by_act, epilogue=K.EPI_MASK, aux=act, mask_scale=1.5)
+        assert torch.equal(by_tiles, by_rows) and torch.equal(by_tiles, by_act)
+        # the reader needs two K steps to cover its early load
+        with pytest.raises(RuntimeError):
+            K.gemm(bf(g[:, :64].contiguous()), bf(w[:, :64].contiguous()), by_tiles, epilogue=K.EPI_MASK_BITS, aux=tiles[:need])
+        with pytest.raises(ValueError):
+            K.gemm(bf(g), bf(w), by_tiles, epilogue=K.EPI_MASK_BITS, aux=tiles[:need - 16])
+    finally:
+        K.gemm_set_tile(0)
+    if lib.paced_gemm_tile_bits_bytes(M, N) == 0:          # not a shape the heuristic gives the 256x256 kernel
+        assert ((M + 255) // 256) * ((N + 255) // 256) < 200
+        with pytest.raises(ValueError):
+            K.gemm(bf(g), bf(w), by_tiles, epilogue=K.EPI_MASK_BITS, aux=tiles[:need])
+    else:
+        assert tuple(K.sign_bits_buffer(M, N, DEV).shape) == (need,)
+
+
 @pytest.mark.parametrize("splits", [1, 3, 8])
 def test_gemm_weight_gradient_atomic_split(splits, tile):
     Mtok, No, Ko = 1000, 136, 192                     # dW[No,Ko] = dY[Mtok,No]^T X[Mtok,Ko]

@@ -6,7 +6,9 @@ spill or reuse those registers before the data has landed.  This script walks th
 reports every instruction that touches the destination registers of an asm `global_load_*` between the load and
 the hand-written `s_waitcnt vmcnt(N) ; hidden-load wait` that releases it (a counted wait releases the oldest pending load, vmcnt(0)
 all of them), and checks every counted wait: N must not exceed the number of vector-memory instructions issued after
-the load it releases, or the wait could return before the data has landed.
+the load it releases, or the wait could return before the data has landed.  The load of a tile's mask bits ahead of
+the phased kernel's K loop has no wait of its own (the loop's counted waits cover it, being younger): it is released by
+the asm comment "tile mask bits arrived" after the loop, and nothing may touch its registers before that.
 
 usage: audit_asm_loads.py gemm.s      (hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S gemm.hip)
 """
@@ -28,6 +30,7 @@ def regs_of(text):
 
 def main(path):
     kernel, in_asm, pending, bad, loads, vm_seq = None, False, [], 0, 0, 0
+    markers_without_load = {}
     for ln, line in enumerate(open(path), 1):
         s = line.strip()
         if s.startswith("_Z") and ":" in s.split(";")[0]:
@@ -38,6 +41,12 @@ def main(path):
             continue
         if s.startswith(";;#ASMEND"):
             in_asm = False
+            continue
+        if in_asm and s.startswith("; tile mask bits arrived"):
+            if pending:
+                pending.pop(0)
+            else:
+                markers_without_load[kernel] = markers_without_load.get(kernel, 0) + 1
             continue
         if not s or s.startswith(";") or s.startswith("."):
             continue
@@ -73,6 +82,11 @@ def main(path):
             if hit:
                 bad += 1
                 print(f"{path}:{ln}: {kernel}: touches v{sorted(hit)} of the load at line {at} before its wait: {s}")
+    # the kernels that read a tile-ordered mask (epilogue 6) must pair every marker with a load
+    for k, n in markers_without_load.items():
+        if "ELi6EE" in k:
+            bad += n
+            print(f"{path}: {k}: {n} mask markers without a pending load")
     print(f"{loads} hidden loads, {bad} violations")
     return 1 if bad else 0
 

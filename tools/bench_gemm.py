@@ -27,6 +27,9 @@ if os.environ.get("EXTRA"):     # the same products with cheaper epilogues: what
         ("wi    NT plain", 0, 0, K.EPI_BF16, M, 3072, 768),
         ("wi    NT relu p=0", 0, 0, K.EPI_RELU_DROP, M, 3072, 768),
         ("dact  NN bits", 0, 1, K.EPI_MASK_BITS, M, 3072, 768),
+        ("dact  NN tilebits", 0, 1, K.EPI_MASK_BITS, M, 3072, 768),      # tile-ordered bit matrix (256x256 kernel only)
+        ("wi    NT relu+bits", 0, 0, K.EPI_RELU_DROP, M, 3072, 768),
+        ("wi    NT relu+tilebits", 0, 0, K.EPI_RELU_DROP, M, 3072, 768),
         ("dact  NN plain", 0, 1, K.EPI_BF16, M, 3072, 768),
     ]
 
@@ -50,11 +53,18 @@ def main():
         b = rn(Kc, C) if tb else rn(C, Kc)
         out = torch.zeros(R, C, device=dev, dtype=torch.float32 if epi in (K.EPI_F32, K.EPI_ATOMIC_F32) else torch.bfloat16)
         aux = rn(R, C) if epi in (K.EPI_RES_DROP, K.EPI_MASK) else None
-        if epi == K.EPI_MASK_BITS:
+        if epi == K.EPI_MASK_BITS or "bits" in name:
             aux = torch.randint(0, 256, (R, C // 8), device=dev, dtype=torch.uint8)
+        tiled = "tilebits" in name
+        if tiled:
+            K.gemm_set_tile(256)
+            aux = torch.randint(0, 256, (K._lib.load().paced_gemm_tile_bits_bytes(R, C),), device=dev, dtype=torch.uint8)
         drop = 0.1 if epi in (K.EPI_RES_DROP, K.EPI_RELU_DROP) and "p=0" not in name else 0.0
         for rnd in range(3):
             for tile in TILES:
+                if tiled and tile != 256:
+                    res.setdefault((name, tile), []).append(float("nan"))
+                    continue
                 K.gemm_set_tile(tile)
                 sp = 0 if epi == K.EPI_ATOMIC_F32 else 1
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
