@@ -698,9 +698,17 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = bf2f(aux[n & 7][e]) > 0.f ? t[e] : (bf16)0.f;
         } else if (EPI == EPI_MASK_BITS) {
+            // bit e of the byte keeps element e: every pair of elements is one register, masked by (sign-extended bit 2j,
+            // sign-extended bit 2j + 1) in its halves; a masked element becomes +0, as a select would make it
             const uint32_t byte = TILED ? tbits[n >> 2] >> ((n & 3) * 8) : mbits[n & 7];
+            u32x4 tw = __builtin_bit_cast(u32x4, t);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = ((byte >> e) & 1u) ? t[e] : (bf16)0.f;
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = (uint32_t)((int32_t)(byte << (31 - 2 * j)) >> 31);
+                const uint32_t hi = (uint32_t)((int32_t)(byte << (30 - 2 * j)) >> 31);
+                tw[j] &= (lo & 0xffffu) | (hi & 0xffff0000u);
+            }
+            t = __builtin_bit_cast(bf16x8, tw);
         }
         const int m = m0 + CfgPhased::moff(wr, i) + q * 8 + rr;
         const bool ok = FULL || (m < p.M && col_ok);
