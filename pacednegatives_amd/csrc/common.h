@@ -62,13 +62,19 @@ __host__ __device__ __forceinline__ uint32_t paced_mad24(uint32_t a, uint32_t c,
 #endif
 }
 // the state shared by the four elements of quad number `quad`
-__host__ __device__ __forceinline__ uint32_t paced_drop_state(uint32_t seed, uint64_t quad) {
-    const uint32_t hi = (uint32_t)(quad >> 32) & 0xffffffu;
-    uint32_t x = paced_mad24(hi, 0x9e3779u, (uint32_t)quad ^ seed);
+__host__ __device__ __forceinline__ uint32_t paced_drop_mix(uint32_t x) {
     x ^= x >> 16; x = paced_mad24(x, 0xeb352du, x);
     x ^= x >> 13; x = paced_mad24(x, 0x2c1b3du, x);
     x ^= x >> 12;
     return x;
+}
+__host__ __device__ __forceinline__ uint32_t paced_drop_state(uint32_t seed, uint64_t quad) {
+    const uint32_t hi = (uint32_t)(quad >> 32) & 0xffffffu;
+    return paced_drop_mix(paced_mad24(hi, 0x9e3779u, (uint32_t)quad ^ seed));
+}
+// the same state for a quad number below 2^32 (a tensor of fewer than 2^34 elements): its high word contributes nothing
+__host__ __device__ __forceinline__ uint32_t paced_drop_state32(uint32_t seed, uint32_t quad) {
+    return paced_drop_mix(quad ^ seed);
 }
 // value of element e (0..3) of a quad with state y: kept iff value >= DropCfg::limit
 template <int E> __host__ __device__ __forceinline__ uint32_t paced_drop_value(uint32_t y) {
@@ -117,6 +123,14 @@ __device__ __forceinline__ void drop_factor4_on(const DropCfg& d, uint64_t idx4,
     drop_keep4_on(d, idx4, k);
 #pragma unroll
     for (int e = 0; e < 4; ++e) f[e] = k[e] ? d.scale : 0.f;
+}
+// factors of quad number `quad` < 2^32, dropout known to be on
+__device__ __forceinline__ void drop_factor4_on32(const DropCfg& d, uint32_t quad, float (&f)[4]) {
+    const uint32_t y = paced_drop_state32(d.seed, quad);
+    f[0] = paced_drop_value<0>(y) >= d.limit ? d.scale : 0.f;
+    f[1] = paced_drop_value<1>(y) >= d.limit ? d.scale : 0.f;
+    f[2] = paced_drop_value<2>(y) >= d.limit ? d.scale : 0.f;
+    f[3] = paced_drop_value<3>(y) >= d.limit ? d.scale : 0.f;
 }
 __device__ __forceinline__ void drop_factor4(const DropCfg& d, uint64_t idx4, float (&f)[4]) {
     if (d.thresh == 0) { f[0] = f[1] = f[2] = f[3] = 1.f; return; }

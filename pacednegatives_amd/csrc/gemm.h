@@ -33,6 +33,7 @@ struct GemmParams {
     float alpha;       // scales acc before the epilogue
     float mask_scale;
     DropCfg drop;
+    int drop_narrow;   // the output has at most 2^34 elements: dropout's quad numbers fit 32 bits
     // pool scorer only
     unsigned long long* tk_cand;
     unsigned int* tk_cnt;

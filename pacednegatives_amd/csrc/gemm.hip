@@ -661,13 +661,14 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
     // 16-row block i as bf16 in the MFMA layout (4 consecutive columns of one row per lane and 16-column group)
     auto convert = [&](int i, bf16x4 (&o)[4]) {
         const uint64_t drow = (uint64_t)(m0 + CfgPhased::moff(wr, i) + mw) * (uint64_t)p.N + (uint64_t)(n0 + wc * 64 + g * 4);
+        const uint32_t qrow = (uint32_t)(drow >> 2);          // quad number: the host sends outputs of more than 2^34 elements elsewhere
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 v = acc[i][j] * scale;
             if (EPI == EPI_RELU_DROP) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
             if (has_drop) {
                 float f[4];
-                drop_factor4(p.drop, drow + j * 16, f);
+                drop_factor4_on32(p.drop, qrow + j * 4, f);
                 v *= f32x4{f[0], f[1], f[2], f[3]};
             }
             o[j] = __builtin_convertvector(v, bf16x4);
@@ -1049,7 +1050,9 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
     const bool rows16 = (EPI == EPI_F32 || EPI == EPI_ATOMIC_F32 || EPI == EPI_TOPK_DENSE || EPI == EPI_TOPK_FILTER) ||
                         (p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                          (!(EPI == EPI_RES_DROP || EPI == EPI_MASK) || (p.ldaux % 8 == 0 && ((uintptr_t)p.aux & 15) == 0)));
-    if (large && rows16) return launch_cfg<CfgPhased, TA, TB, EPI>(p, splits, stream);
+    // ... and numbers dropout's quads with 32 bits
+    const bool quads32 = !(EPI == EPI_RES_DROP || EPI == EPI_RELU_DROP) || p.drop.thresh == 0 || p.drop_narrow;
+    if (large && rows16 && quads32) return launch_cfg<CfgPhased, TA, TB, EPI>(p, splits, stream);
     if ((EPI == EPI_RELU_DROP || EPI == EPI_MASK_BITS) && p.aux && p.ldaux < 0) {
         paced_set_error("paced_gemm_bf16: a tile-ordered bit matrix (ldaux = -1) needs a shape that takes the 256x256 kernel; ask paced_gemm_tile_bits_bytes first");
         return PACED_ERR_ARG;
@@ -1091,6 +1094,7 @@ extern "C" int paced_gemm_last_kernel(void) { return g_last_kernel; }
 
 extern "C" long long paced_gemm_tile_bits_bytes(int M, int N) {
     if (M < 256 || N < 256 || N % 8 != 0 || g_force_tile == 128 || g_force_tile == 64) return 0;
+    if ((unsigned long long)M * (unsigned long long)N > (1ull << 34)) return 0;      // dropout would send the writer elsewhere
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256);
     if (g_force_tile != 256 && t256 < 200) return 0;
     return t256 * 8192;
@@ -1168,6 +1172,7 @@ static int gemm_entry(const void* A, const void* B, void* C, const void* aux,
     p.k_per_split = K; p.a_heads = a_heads; p.b_heads = b_heads; p.c_heads = c_heads;
     p.alpha = alpha; p.mask_scale = mask_scale;
     p.drop = make_drop(drop_p, drop_seed);
+    p.drop_narrow = (unsigned long long)M * (unsigned long long)N <= (1ull << 34);
     p.tk_cand = nullptr; p.tk_cnt = nullptr; p.tk_thr = nullptr; p.tk_cap = 0; p.tk_row_base = 0;
     p.batch = batch; p.strideA = strideA; p.strideB = strideB; p.strideC = strideC;
     return paced_gemm_launch(p, trans_a != 0, trans_b != 0, epilogue, splits, (hipStream_t)stream);

@@ -190,7 +190,7 @@ int pool_topk_sweep(const void* queries, const void* pool, int Q, long long Np, 
                     int cap, int ch_max, hipStream_t s) {
     GemmParams p = {};
     p.B = (const bf16*)queries; p.N = Q; p.K = D; p.lda = D; p.ldb = D; p.ldc = 0;
-    p.k_per_split = D; p.alpha = 1.f; p.mask_scale = 1.f; p.drop = make_drop(0.f, 0);
+    p.k_per_split = D; p.alpha = 1.f; p.mask_scale = 1.f; p.drop = make_drop(0.f, 0); p.drop_narrow = 0;
     p.tk_cand = cand; p.tk_cnt = cnt; p.tk_thr = thr; p.tk_cap = cap;
     p.batch = 1;
 
