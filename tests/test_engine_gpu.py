@@ -190,6 +190,40 @@ def test_forward_backward_at_real_widths(d, H, ff):
     within(f"d={d} worst per-tensor gradient L2 error", worst, 5e-2)
 
 
+def test_tile_ordered_sign_bits_give_the_same_gradients(monkeypatch):
+    """At token counts that give the FFN products the 256x256 kernel, the ReLU sign bits travel from the forward to the
+    backward pass in that kernel's own order (PACED_TILE_BITS, default on); the row-major bit matrix must give the same
+    logits and, up to the order of the fp32 atomics of the weight gradients, the same gradients (dropout on)."""
+    from pacednegatives_amd import kernels as K
+    from pacednegatives_amd.config import T5Dims
+    from pacednegatives_amd.model import T5ForConditionalGenerationHIP
+    d, H, ff = 768, 12, 3072
+    dims = T5Dims(6400, d, 64, H, ff, 1, 1)
+    rd = RefDims(6400, d, 64, H, ff, 1, 1)
+    m = T5ForConditionalGenerationHIP(dims, device="cuda", init=False)
+    m.params.load_hf(init_params(rd, 5))
+    B, S = 20, 256                                   # 5120 tokens x 3072: 240 tiles
+    g = torch.Generator().manual_seed(17)
+    ids = torch.randint(2, 6400, (B, S), generator=g)
+    labels = torch.tensor([[1176, 1], [6136, 1]] * (B // 2))
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PACED_TILE_BITS", mode)
+        assert K.sign_bits_buffer(B * S, ff, "cuda").dim() == (1 if mode == "1" else 2)
+        st = m.engine.forward(ids, labels, save=True, drop_p=0.1, seed=9)
+        loss = torch.empty(B * 2, device="cuda")
+        dl = torch.empty(B * 2, 6400, device="cuda", dtype=torch.bfloat16)
+        K.cross_entropy(st.logits, labels.cuda().view(-1).contiguous(), loss, dl, gscale=1.0 / (B * 2))
+        m.params.g32.zero_()
+        m.engine.backward(st, dl)
+        torch.cuda.synchronize()
+        runs[mode] = (st.logits.clone(), m.params.g32.clone())
+    assert torch.equal(runs["1"][0], runs["0"][0])
+    ga, gb = runs["1"][1], runs["0"][1]
+    assert float(ga.norm()) > 0
+    within("gradient L2 difference between the two bit orders", float((ga - gb).norm() / gb.norm()), 1e-6)
+
+
 @pytest.mark.parametrize("seed", [77, 83, 86])
 def test_dropout_masks_replayed_in_the_oracle(seed):
     """Dropout ON: the engine never stores a mask, forward and backward kernels recompute it from (seed, site, index).
