@@ -14,6 +14,7 @@
 // ((n*H + h)*Tq + q)*Tk4 + key, Tk4 = Tk rounded up to a multiple of 4 (so that the 4 keys a lane holds
 // in consecutive registers always share one hash evaluation), identical in forward and backward.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -212,11 +213,19 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
 
 }  // namespace
 
+// State of dropout quad number `quad` of the probability tensor.  WIDE = false: the tensor has at most 2^34 elements, the
+// quad number fits 32 bits and its high word would contribute nothing (same state, and the index arithmetic that feeds
+// only this call narrows to 32 bits).
+template <bool WIDE>
+__device__ __forceinline__ uint32_t attn_drop_state(uint32_t seed, uint64_t quad) {
+    return WIDE ? paced_drop_state(seed, quad) : paced_drop_state32(seed, (uint32_t)quad);
+}
+
 // (kernel templates stay outside the anonymous namespace so that their host stubs are emitted)
 // =================================================================================== forward
 // grid (ceil(S/128), H, N), 256 threads: wave w owns queries qb + 32w .. +32.  DROP: dropout on the
 // probabilities is compiled in (no per-element branches in the other instantiation).
-template <bool DROP>
+template <bool DROP, bool WIDE>
 __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lK = smem;                 // 64 x 64 row image
@@ -282,7 +291,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
         const float m_log2 = m_new * LOG2E;          // exp(s - m) as exp2(s * log2(e) - m * log2(e)): one fma, one v_exp_f32
-        const uint64_t dbase = (((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3);   // key rows padded to quads
+        const uint64_t qbase = ((((uint64_t)n * a.H + h) * S + qc) * (uint64_t)((S + 3) & ~3)) >> 2;   // key rows padded to quads
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -290,7 +299,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
                 bool keep[4] = {true, true, true, true};      // the 1/(1-p) scale of kept probabilities goes into the final normalisation
                 if (DROP) {
                     const int key = kt * 64 + 32 * j + acc_row(r, hh);      // multiple of 4; registers r+1..r+3 hold key+1..key+3
-                    drop_keep4_on(a.drop, dbase + key, keep);
+                    drop_keep4_of_state(a.drop, attn_drop_state<WIDE>(a.drop.seed, qbase + (uint64_t)(key >> 2)), keep);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -348,7 +357,7 @@ __device__ __forceinline__ void diag_step(const f32x16& ds, int j, float& all, f
 }
 
 // grid (ceil(S/128), H, N): wave w owns keys kb + 32w .. +32 and sweeps all queries in tiles of 32.
-template <bool DROP>
+template <bool DROP, bool WIDE>
 __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PAD = 32;        // table entries in front of index 0: query rows past S (last tile) index below it
@@ -471,7 +480,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             // 4 hashes: lane (l & 3) evaluates the one of query q4 + (l & 3) and a quad broadcast hands
             // each to the other three.
             uint32_t y = 0;
-            if (DROP) y = paced_drop_state(a.drop.seed, hq + (uint64_t)(8 * rg) * S4q);
+            if (DROP) y = attn_drop_state<WIDE>(a.drop.seed, hq + (uint64_t)(8 * rg) * S4q);
             uint32_t ys[4];                            // states of queries q4 .. q4+3 (quad broadcasts of lanes 0..3)
             ys[0] = quad_bcast<0>(y); ys[1] = quad_bcast<1>(y); ys[2] = quad_bcast<2>(y); ys[3] = quad_bcast<3>(y);
 #pragma unroll
@@ -567,7 +576,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
 
 // ================================================================================ backward: dQ
 // grid (ceil(S/128), H, N): wave w owns queries qb + 32w .. +32 and sweeps all keys in tiles of 64.
-template <bool DROP>
+template <bool DROP, bool WIDE>
 __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* lKr = smem;               // 64 x 64 row image of K
@@ -657,7 +666,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {           // registers 4rg .. 4rg+3 hold 4 consecutive keys: one hash evaluation
                 bool keep[4] = {true, true, true, true};
-                if (DROP) drop_keep4_on(a.drop, (hq + (uint64_t)(kt * 16 + 8 * j + 2 * rg)) << 2, keep);
+                if (DROP) drop_keep4_of_state(a.drop, attn_drop_state<WIDE>(a.drop.seed, hq + (uint64_t)(kt * 16 + 8 * j + 2 * rg)), keep);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * rg + e;
@@ -1218,6 +1227,14 @@ int check_common(const char* fn, int N, int S, int H, int dk) {
 
 }  // namespace
 
+// The probability tensor of N x H heads of S x (S rounded up to 4) has more than 2^34 elements: dropout's quad numbers
+// need their high word (PACED_ATTN_WIDE_DROPOUT=1 forces that instantiation, for tests: same masks below 2^34).
+static bool wide_dropout_index(int N, int H, int S) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("PACED_ATTN_WIDE_DROPOUT"); forced = (e && atoi(e) != 0) ? 1 : 0; }
+    return forced || (unsigned long long)N * H * S * ((S + 3) & ~3) > (1ull << 34);
+}
+
 extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, long long hs, void* ctx, int ldo, long long hso, float* lse,
                                   const float* bias_tbl, int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
     if (int e = check_common("paced_enc_attn_fwd", N, S, H, dk)) return e;
@@ -1230,8 +1247,9 @@ extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, i
     a.N = N; a.S = S; a.H = H; a.drop = make_drop(drop_p, drop_seed);
     const size_t smem = 16384 + (size_t)(2 * S + 64) * 4;
     const dim3 grid((S + 127) / 128, H, N);
-    if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_fwd_kernel<true>), grid, dim3(256), smem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((enc_attn_fwd_kernel<false>), grid, dim3(256), smem, (hipStream_t)stream, a);
+    if (!a.drop.thresh) hipLaunchKernelGGL((enc_attn_fwd_kernel<false, false>), grid, dim3(256), smem, (hipStream_t)stream, a);
+    else if (wide_dropout_index(N, H, S)) hipLaunchKernelGGL((enc_attn_fwd_kernel<true, true>), grid, dim3(256), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((enc_attn_fwd_kernel<true, false>), grid, dim3(256), smem, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }
@@ -1258,18 +1276,22 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
     if (smem1 > 65536) {      // 300 to 512 tokens (eight arrays of sums), or beyond ~1900
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
             if (e != hipSuccess) { paced_set_error("paced_enc_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return PACED_ERR_HIP; }
             attr_set = true;
         }
     }
-    if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<true>), grid, dim3(256), smem1, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<false>), grid, dim3(256), smem1, (hipStream_t)stream, a);
+    const bool wide = wide_dropout_index(N, H, S);
+    if (!a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<false, false>), grid, dim3(256), smem1, (hipStream_t)stream, a);
+    else if (wide) hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<true, true>), grid, dim3(256), smem1, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((enc_attn_bwd_dkdv_kernel<true, false>), grid, dim3(256), smem1, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
     const size_t smem2 = 24576 + (size_t)(2 * S + 64 + 128) * 4;
-    if (a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<true>), grid, dim3(256), smem2, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<false>), grid, dim3(256), smem2, (hipStream_t)stream, a);
+    if (!a.drop.thresh) hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<false, false>), grid, dim3(256), smem2, (hipStream_t)stream, a);
+    else if (wide) hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<true, true>), grid, dim3(256), smem2, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((enc_attn_bwd_dq_kernel<true, false>), grid, dim3(256), smem2, (hipStream_t)stream, a);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }

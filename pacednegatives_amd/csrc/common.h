@@ -110,12 +110,15 @@ __device__ __forceinline__ float drop_factor(const DropCfg& d, uint64_t idx) {
     return paced_drop_bits(d.seed, idx) >= d.thresh ? d.scale : 0.f;
 }
 // keep decisions of the aligned quad (idx4 a multiple of 4 .. idx4 + 3) from ONE state (dropout known to be on)
-__device__ __forceinline__ void drop_keep4_on(const DropCfg& d, uint64_t idx4, bool (&k)[4]) {
-    const uint32_t y = paced_drop_state(d.seed, idx4 >> 2);
+// ... from the quad's state
+__device__ __forceinline__ void drop_keep4_of_state(const DropCfg& d, uint32_t y, bool (&k)[4]) {
     k[0] = paced_drop_value<0>(y) >= d.limit;
     k[1] = paced_drop_value<1>(y) >= d.limit;
     k[2] = paced_drop_value<2>(y) >= d.limit;
     k[3] = paced_drop_value<3>(y) >= d.limit;
+}
+__device__ __forceinline__ void drop_keep4_on(const DropCfg& d, uint64_t idx4, bool (&k)[4]) {
+    drop_keep4_of_state(d, paced_drop_state(d.seed, idx4 >> 2), k);
 }
 // factors of the aligned quad, dropout known to be on (no uniform branch per call)
 __device__ __forceinline__ void drop_factor4_on(const DropCfg& d, uint64_t idx4, float (&f)[4]) {
