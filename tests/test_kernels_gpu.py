@@ -621,6 +621,22 @@ def test_enc_attention_head_major_operands_give_the_same_bits(N, S, H, p, what):
     assert (dtbl0 - dtbl1).abs().max().item() <= 1e-5 * dtbl0.abs().max().item()      # order of the atomic adds
 
 
+def test_enc_attention_64_bit_dropout_numbering_gives_the_same_masks():
+    """The encoder attention numbers its dropout quads with 32 bits up to 2^34 probabilities and with 64 bits beyond;
+    PACED_ATTN_WIDE_DROPOUT=1 (read once per process) forces the 64-bit kernels, so a child process runs the dropout
+    cases of test_enc_attention_fwd_bwd, which replay the masks through the library's mask function, under it."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PACED_ATTN_WIDE_DROPOUT="1")
+    cmd = [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+           "-k", "test_enc_attention_fwd_bwd or test_enc_attention_head_major"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
 def test_enc_attention_rescale_branch_forced():
     """One key far above the rest in a late tile forces the online-softmax running-max update."""
     N, S, H, I = 1, 192, 1, 64
