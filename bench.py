@@ -242,46 +242,6 @@ def run_mining(args, rank, world, device):
     return out
 
 
-def launch_ranks(n: int) -> int:
-    """``python bench.py --gpus N`` without a torchrun environment: start N fresh processes of this script, one per
-    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relay rank 0's JSON line and return non-zero if any rank
-    failed.  The parent makes no GPU call, before or after."""
-    import socket
-    import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    import threading
-    chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    failed = False
-    while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):      # a dead rank leaves the others waiting in a collective
-            failed = True
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            break
-        time.sleep(0.2)
-    codes = [p.wait() for p in procs]
-    reader.join(timeout=10)
-    for line in b"".join(chunks).decode(errors="replace").splitlines():
-        # stdout carries rank 0's JSON line only; whatever else a rank printed there (gloo's connection notice) goes to stderr
-        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad or failed:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
-    return 0
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -299,13 +259,19 @@ def main():
     ap.add_argument("--mine_queries", type=int, default=4096)
     ap.add_argument("--mine_k", type=int, default=1000)
     ap.add_argument("--mine_iters", type=int, default=2)
+    ap.add_argument("--launch-timeout", dest="launch_timeout", type=float, default=1500.0,
+                    help="seconds after which a self-launched multi-rank run is stopped")
     args = ap.parse_args()
 
     if os.environ.get("PACED_HANG_DUMP"):        # debugging aid: dump every thread's stack and exit after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["PACED_HANG_DUMP"]), exit=True)
     if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus))         # this process never touches the GPU
+        # `python bench.py --gpus N` without a torchrun environment: N fresh rank processes of this script, rank 0's JSON
+        # line relayed; all ranks are stopped (exit code 124) if the run exceeds --launch-timeout seconds.  This
+        # process never touches the GPU.
+        from pacednegatives_amd.launcher import launch_ranks
+        raise SystemExit(launch_ranks(args.gpus, timeout_s=args.launch_timeout, json_only_stdout=True))
     # stdout carries the JSON line and nothing else: libraries write notices there (RCCL prints the path of its
     # shared object when the first communicator is made, gloo its connections), so file descriptor 1 points at
     # stderr until the line is ready

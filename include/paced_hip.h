@@ -83,8 +83,36 @@ int paced_gemm_bf16_batched(const void* A, const void* B, void* C,
                             int trans_a, int trans_b, int epilogue, float alpha, int splits,
                             int batch, long long strideA, long long strideB, long long strideC, void* stream);
 
-/* Tile selection of paced_gemm_bf16: 0 = heuristic (default), 64 = 64x64 tiles, 128 = 128x128 tiles, 256 = 256x256
- * phased tiles (one workgroup per CU, LDS ring).  Process-wide; meant for benchmarking and tests. */
+/* One entry point for every form above (plain: head strides 0, batch 1; head-major: a/b/c_heads; batched: batch and
+ * strides) with PER-CALL launch options.  The same products as paced_gemm_bf16 (same reference call sites); what the
+ * options choose never changes a result bit except through the kernel that is taken (tile edge, ring variant).
+ *   grid_limit  < 0: the process default;  0: one workgroup per compute unit;  n > 0: at most n workgroups for a 256x256
+ *               phased launch.  A phased workgroup keeps its compute unit for the whole launch, so the units a smaller
+ *               grid leaves out are where kernels of other streams can start meanwhile: LCEModel.training_step passes a
+ *               limit for the no-grad forwards (lceT5.py:131-133) that run beside the two-token decoder of the pass that
+ *               keeps state.
+ *   tile        < 0: the process default;  0: heuristic;  64 / 128 / 256: force that tile configuration.
+ *   ring        < 0: the process default;  0 / 1: ring variant of the small-tile kernels off / on.
+ *   kernel      OUT: the kernel this call launched, as paced_gemm_last_kernel() encodes it (0 if the call failed).
+ * opts may be NULL (all process defaults).  The options are read on the calling thread for this call only: nothing another
+ * thread launches meanwhile sees them. */
+typedef struct paced_gemm_opts {
+    int grid_limit;
+    int tile;
+    int ring;
+    int kernel;
+} paced_gemm_opts;
+int paced_gemm_bf16_ex(const void* A, const void* B, void* C, const void* aux,
+                       int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                       int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
+                       float drop_p, uint32_t drop_seed, int splits,
+                       long long a_heads, long long b_heads, long long c_heads,
+                       int batch, long long strideA, long long strideB, long long strideC,
+                       paced_gemm_opts* opts, void* stream);
+
+/* ---- process-wide defaults of the options above: for benchmarks and tests only (the training step passes its options per
+ * call).  Tile selection: 0 = heuristic (default), 64 = 64x64 tiles, 128 = 128x128 tiles, 256 = 256x256 phased tiles (one
+ * workgroup per CU, LDS ring). */
 int paced_gemm_set_tile(int tile);
 
 /* Ring variant of the 64x64 / 128x128 kernels (a workgroup keeps several K steps in flight in its own LDS; taken when
@@ -93,12 +121,11 @@ int paced_gemm_set_tile(int tile);
  * Process-wide; meant for benchmarking and tests. */
 int paced_gemm_set_ring(int on);
 
-/* Upper limit on the workgroups of a 256x256 phased launch: 0 = one per compute unit (default; PACED_GEMM_GRID=n sets
- * a limit at load).  A phased workgroup keeps its compute unit for the whole launch, so the units a smaller grid leaves
- * out are where kernels of other streams can start meanwhile: LCEModel.training_step sets a limit around the no-grad
- * forwards (lceT5.py:131-133) that run beside the two-token decoder of the pass that keeps state.  Process-wide, read
- * at launch time on the calling thread. */
+/* Process default of the upper limit on the workgroups of a 256x256 phased launch: 0 = one per compute unit (default;
+ * PACED_GEMM_GRID=n sets a limit at load).  Read at launch time by calls that pass no limit of their own.
+ * paced_gemm_get_grid returns the current default. */
 int paced_gemm_set_grid(int workgroups);
+int paced_gemm_get_grid(void);
 
 /* Size in bytes of a TILE-ORDERED bit matrix for an M x N product, or 0 when a product of that shape would not take the
  * 256x256 phased kernel (then only the row-major form, ldaux >= N/8, is accepted).  The sign-bit matrix that epilogue 2
@@ -110,7 +137,7 @@ int paced_gemm_set_grid(int workgroups);
  * so that the epilogue does not wait on memory.  Writer and reader must have the same M and N. */
 long long paced_gemm_tile_bits_bytes(int M, int N);
 
-/* Which kernel the calling process's most recent paced_gemm_bf16[_batched] launch used: the tile edge (64, 128 or 256;
+/* Which kernel the calling THREAD's most recent paced_gemm_bf16[_batched|_heads|_ex] launch used: the tile edge (64, 128 or 256;
  * 256 is the phased kernel), plus 1 when the ring variant took it; 0 before the first launch.  For profilers that
  * attribute launch times to kernels (bench.py's roofline leg). */
 int paced_gemm_last_kernel(void);

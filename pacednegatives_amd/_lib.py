@@ -15,6 +15,15 @@ LIB_PATH = os.environ.get("PACED_HIP_LIB") or os.path.join(_HERE, "lib", "libpac
 
 _vp, _i, _f, _u32, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, C.c_longlong
 
+class GemmOpts(C.Structure):
+    """``struct paced_gemm_opts`` of include/paced_hip.h (a negative input field = the process default)."""
+    _fields_ = [("grid_limit", _i), ("tile", _i), ("ring", _i), ("kernel", _i)]
+
+
+# paced_abi_version() this binding was written against: argument lists changed between versions, so a library of another
+# version that happens to export every symbol would be called with shifted arguments
+EXPECTED_ABI = 4
+
 # name -> (restype, argtypes); must list every symbol include/paced_hip.h declares
 SIGNATURES = {
     "paced_abi_version": (_i, []),
@@ -22,9 +31,12 @@ SIGNATURES = {
     "paced_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _u32, _i, _vp]),
     "paced_gemm_bf16_heads": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _u32, _i, _ll, _ll, _ll, _vp]),
     "paced_gemm_bf16_batched": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _ll, _ll, _ll, _vp]),
+    "paced_gemm_bf16_ex": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _u32, _i, _ll, _ll, _ll,
+                                _i, _ll, _ll, _ll, C.POINTER(GemmOpts), _vp]),
     "paced_gemm_set_tile": (_i, [_i]),
     "paced_gemm_set_ring": (_i, [_i]),
     "paced_gemm_set_grid": (_i, [_i]),
+    "paced_gemm_get_grid": (_i, []),
     "paced_gemm_last_kernel": (_i, []),
     "paced_gemm_tile_bits_bytes": (_ll, [_i, _i]),
     "paced_rmsnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _u32, _vp]),
@@ -81,6 +93,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.paced_abi_version()
+    if got != EXPECTED_ABI:
+        raise PacedHipError(f"{LIB_PATH} has ABI version {got}, this binding expects {EXPECTED_ABI}: rebuild the library "
+                            "(python __graft_entry__.py) or point PACED_HIP_LIB at a build of this source tree")
     _lib = lib
     return lib
 

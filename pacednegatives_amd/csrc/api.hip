@@ -13,4 +13,4 @@ void paced_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* paced_last_error(void) { return g_err; }
-extern "C" int paced_abi_version(void) { return 3; }
+extern "C" int paced_abi_version(void) { return 4; }

@@ -1273,8 +1273,9 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
     const dim3 grid((S + 127) / 128, H, N);
     // two staging areas, the bias table, the bias-gradient sums (8 arrays up to 512 tokens, one beyond)
     const size_t smem1 = 2 * (16384 + 256) + (size_t)(32 + (1 + (S <= 512 ? 8 : 1)) * (2 * S + 160)) * 4;
-    if (smem1 > 65536) {      // 300 to 512 tokens (eight arrays of sums), or beyond ~1900
-        static bool attr_set = false;
+    if (smem1 > 65536) {      // 367 to 512 tokens (eight arrays of sums), or beyond 1928
+        static PerDeviceOnce once;
+        bool& attr_set = once.flag();
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_attn_bwd_dkdv_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
@@ -1344,7 +1345,8 @@ extern "C" int paced_cross_attn_bwd(const void* qc, int ldq, const void* kv, int
 
 template <int NF, bool BWD>
 static int launch_cross2(const CrossArgs& a, int smem, hipStream_t stream) {
-    static bool attr_set = false;     // one flag per instantiation
+    static PerDeviceOnce once;        // one per instantiation
+    bool& attr_set = once.flag();
     if (!attr_set && smem > 65536) {
         hipError_t e;
         if (BWD) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross2_bwd_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096 + 16384 + 512);

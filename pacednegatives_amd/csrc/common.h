@@ -38,6 +38,17 @@ void paced_set_error(const char* fmt, ...);
         }                                                                  \
     } while (0)
 
+// hipFuncSetAttribute acts on the CURRENT device, so "already done" is kept per device (a process that drives a second
+// GPU would otherwise launch there without the attribute).  Racing threads at worst set the attribute twice.
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool& flag() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+        return done[dev];
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

@@ -926,9 +926,21 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
 
 namespace {
 
+// Process-wide defaults (benchmarks and tests set them through paced_gemm_set_*) and the options of the call under way on
+// this thread (paced_gemm_bf16_ex; a field < 0 = take the process default).  Launch code reads the eff_* functions only.
 int g_force_tile = 0;    // 0 = heuristic, 128 or 256 = forced (paced_gemm_set_tile, for benchmarking)
 int g_grid_limit = 0;    // 0 = one phased workgroup per CU; n > 0: at most n (paced_gemm_set_grid; PACED_GEMM_GRID at load)
 bool g_grid_env_read = false;
+struct CallOpts { int grid_limit = -1, tile = -1, ring = -1; };
+thread_local CallOpts t_call;
+thread_local int t_last_kernel = 0;   // tile of this thread's most recent launch (64, 128, 256), +1 when the ring variant took it
+
+int eff_tile() { return t_call.tile >= 0 ? t_call.tile : g_force_tile; }
+int eff_grid_limit() {
+    if (t_call.grid_limit >= 0) return t_call.grid_limit;
+    if (!g_grid_env_read) { const char* e = getenv("PACED_GEMM_GRID"); if (e && g_grid_limit == 0) g_grid_limit = atoi(e); g_grid_env_read = true; }
+    return g_grid_limit;
+}
 
 int cu_count() {
     static int cached[64] = {0};
@@ -942,9 +954,9 @@ int cu_count() {
     return cached[dev];
 }
 
-int g_last_kernel = 0;   // tile of the most recent launch (64, 128, 256), +1 when the ring variant took it
 int g_ring = -1;         // -1 = not set yet (PACED_GEMM_RING read on first use), 0 off, 1 on (paced_gemm_set_ring)
 bool ring_enabled() {
+    if (t_call.ring >= 0) return t_call.ring != 0;
     if (g_ring < 0) { const char* e = getenv("PACED_GEMM_RING"); g_ring = (e && atoi(e) == 0) ? 0 : 1; }
     return g_ring != 0;
 }
@@ -953,7 +965,8 @@ template <class Cfg, bool TA, bool TB, int EPI, int NS>
 int launch_ring(const GemmParams& p, int ntm, int ntn, int total, hipStream_t stream) {
     constexpr int smem = NS * (Cfg::BM + Cfg::BN) * BK * 2;
     if (smem > 65536) {
-        static bool attr_set = false;
+        static PerDeviceOnce once;
+        bool& attr_set = once.flag();
         if (!attr_set) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<Cfg, TA, TB, EPI, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) { paced_set_error("hipFuncSetAttribute(%d bytes LDS) failed: %s", smem, hipGetErrorString(e)); return PACED_ERR_HIP; }
@@ -961,7 +974,7 @@ int launch_ring(const GemmParams& p, int ntm, int ntn, int total, hipStream_t st
         }
     }
     hipLaunchKernelGGL((gemm_ring_kernel<Cfg, TA, TB, EPI, NS>), dim3(total), dim3(Cfg::WGM * Cfg::WGN * 64), smem, stream, p, ntm, ntn, total);
-    g_last_kernel = Cfg::BM + 1;
+    t_last_kernel = Cfg::BM + 1;
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }
@@ -976,8 +989,8 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
         // At most g_grid_limit workgroups: the compute units the grid leaves out stay free for the kernels of other
         // streams for as long as this launch runs (a phased workgroup holds all of a unit's LDS and registers until
         // the whole launch is over, so nothing else starts on a unit it has taken).
-        if (!g_grid_env_read) { const char* e = getenv("PACED_GEMM_GRID"); if (e && g_grid_limit == 0) g_grid_limit = atoi(e); g_grid_env_read = true; }
-        if (g_grid_limit > 0 && g_grid_limit < slots) slots = g_grid_limit;
+        const int limit = eff_grid_limit();
+        if (limit > 0 && limit < slots) slots = limit;
     }
     constexpr bool RINGABLE = !PHASED && EPI != EPI_TOPK_DENSE && EPI != EPI_TOPK_FILTER;
     const bool ring_on = ring_enabled();
@@ -1012,7 +1025,8 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     }
     constexpr int smem = PHASED ? 163840 : (Cfg::BM + Cfg::BN) * BK * 2;
     if (smem > 65536) {
-        static bool attr_set = false;     // one flag per template instantiation
+        static PerDeviceOnce once;        // one per template instantiation
+        bool& attr_set = once.flag();
         if (!attr_set) {
             hipError_t e;
             if constexpr (PHASED) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_phased_kernel<TA, TB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1023,14 +1037,15 @@ int launch_cfg(GemmParams p, int splits, hipStream_t stream) {
     }
     if constexpr (PHASED) hipLaunchKernelGGL((gemm_phased_kernel<TA, TB, EPI>), dim3(grid), dim3(512), smem, stream, p, ntm, ntn, total);
     else hipLaunchKernelGGL((gemm_bf16_kernel<Cfg, TA, TB, EPI>), dim3(grid), dim3(Cfg::WGM * Cfg::WGN * 64), smem, stream, p, ntm, ntn, total);
-    g_last_kernel = Cfg::BM;
+    t_last_kernel = Cfg::BM;
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }
 
 template <bool TA, bool TB, int EPI>
 int launch(const GemmParams& p, int splits, hipStream_t stream) {
-    if (EPI == EPI_ATOMIC_F32 && splits <= 0 && g_force_tile == 0 && ring_enabled()) {
+    const int force_tile = eff_tile();
+    if (EPI == EPI_ATOMIC_F32 && splits <= 0 && force_tile == 0 && ring_enabled()) {
         // Short contraction into a mid-sized output (the decoder's weight gradients): the launch is bound by the
         // output, every split adds the whole output once more in atomics, and a big tile leaves CUs empty; take
         // 64x64 tiles, no more splits than it takes to give every CU a workgroup, and the ring kernel.
@@ -1039,8 +1054,8 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
         if (ktiles >= 3 && ktiles <= 32 && t64 <= 3LL * cu_count()) return launch_cfg<CfgTiny, TA, TB, EPI>(p, 0, stream);
     }
     bool large;
-    if (g_force_tile == 128) large = false;
-    else if (g_force_tile == 256) large = true;
+    if (force_tile == 128) large = false;
+    else if (force_tile == 256) large = true;
     else {
         // the 256x256 tile pays off once there is about one tile per CU (split slices count for atomics)
         const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.batch;
@@ -1061,7 +1076,7 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     // (with the ring kernel half a grid of 128x128 tiles beats more than two 64x64 tiles per CU: half the operand traffic)
     const int tiny_below = ring_enabled() ? cu_count() / 2 : cu_count();
-    const bool tiny = g_force_tile == 64 || (g_force_tile == 0 && t128 < tiny_below && (EPI != EPI_ATOMIC_F32 || splits == 1));
+    const bool tiny = force_tile == 64 || (force_tile == 0 && t128 < tiny_below && (EPI != EPI_ATOMIC_F32 || splits == 1));
     if (tiny) return launch_cfg<CfgTiny, TA, TB, EPI>(p, splits, stream);
     return launch_cfg<CfgSmall, TA, TB, EPI>(p, splits, stream);
 }
@@ -1090,7 +1105,7 @@ extern "C" int paced_gemm_set_tile(int tile) {
     return PACED_OK;
 }
 
-extern "C" int paced_gemm_last_kernel(void) { return g_last_kernel; }
+extern "C" int paced_gemm_last_kernel(void) { return t_last_kernel; }
 
 extern "C" long long paced_gemm_tile_bits_bytes(int M, int N) {
     if (M < 256 || N < 256 || N % 8 != 0 || g_force_tile == 128 || g_force_tile == 64) return 0;
@@ -1106,6 +1121,8 @@ extern "C" int paced_gemm_set_grid(int workgroups) {
     g_grid_env_read = true;
     return PACED_OK;
 }
+
+extern "C" int paced_gemm_get_grid(void) { return g_grid_limit; }
 
 extern "C" int paced_gemm_set_ring(int on) {
     g_ring = on ? 1 : 0;
@@ -1193,6 +1210,28 @@ extern "C" int paced_gemm_bf16_heads(const void* A, const void* B, void* C, cons
                                      long long a_heads, long long b_heads, long long c_heads, void* stream) {
     return gemm_entry(A, B, C, aux, M, N, K, lda, ldb, ldc, ldaux, trans_a, trans_b, epilogue, alpha, mask_scale,
                       drop_p, drop_seed, splits, stream, 1, 0, 0, 0, a_heads, b_heads, c_heads);
+}
+
+// Mirrors `struct paced_gemm_opts` of include/paced_hip.h.
+struct paced_gemm_opts { int grid_limit, tile, ring, kernel; };
+
+extern "C" int paced_gemm_bf16_ex(const void* A, const void* B, void* C, const void* aux,
+                                  int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
+                                  int trans_a, int trans_b, int epilogue, float alpha, float mask_scale,
+                                  float drop_p, uint32_t drop_seed, int splits,
+                                  long long a_heads, long long b_heads, long long c_heads,
+                                  int batch, long long strideA, long long strideB, long long strideC,
+                                  paced_gemm_opts* opts, void* stream) {
+    if (opts) {
+        PACED_CHECK_ARG(opts->tile < 0 || opts->tile == 0 || opts->tile == 64 || opts->tile == 128 || opts->tile == 256,
+                        "paced_gemm_bf16_ex: opts.tile must be negative (process default), 0 (heuristic), 64, 128 or 256");
+        t_call.grid_limit = opts->grid_limit; t_call.tile = opts->tile; t_call.ring = opts->ring;
+    }
+    const int rc = gemm_entry(A, B, C, aux, M, N, K, lda, ldb, ldc, ldaux, trans_a, trans_b, epilogue, alpha, mask_scale,
+                              drop_p, drop_seed, splits, stream, batch, strideA, strideB, strideC, a_heads, b_heads, c_heads);
+    t_call = CallOpts();
+    if (opts) opts->kernel = rc == PACED_OK ? t_last_kernel : 0;
+    return rc;
 }
 
 extern "C" int paced_gemm_bf16_batched(const void* A, const void* B, void* C,

@@ -54,14 +54,23 @@ def _operand(t, name):
     return t.shape[0], t.shape[1], _rows2d(t, name), 0
 
 
+def _gemm_opts(grid_limit, tile, ring):
+    """paced_gemm_opts for one call, or None when every option is left to the process default."""
+    if grid_limit is None and tile is None and ring is None and PROFILE is None:
+        return None
+    return _lib.GemmOpts(-1 if grid_limit is None else int(grid_limit), -1 if tile is None else int(tile),
+                         -1 if ring is None else int(bool(ring)), 0)
+
+
 def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, alpha=1.0, mask_scale=1.0,
-         drop_p=0.0, drop_seed=0, splits=1):
+         drop_p=0.0, drop_seed=0, splits=1, grid_limit=None, tile=None, ring=None):
     """c = alpha * op(a) op(b) with a fused epilogue (see include/paced_hip.h).
 
     aux is the bf16 residual / mask operand of EPI_RES_DROP / EPI_MASK, or a uint8 [M, N/8] bit matrix
     (bit n%8 of byte n//8 of row m <-> element (m, n)): written by EPI_RELU_DROP with the sign of its
     output, read by EPI_MASK_BITS; a 1-D uint8 aux is a tile-ordered bit matrix from sign_bits_buffer.
     a, c and a transposed b may be head-major 3-D tensors (see _operand).
+    grid_limit / tile / ring: launch options of THIS call (``paced_gemm_opts``; None = the process default).
     """
     lib = _lib.load()
     bits = epilogue in (EPI_RELU_DROP, EPI_MASK_BITS)
@@ -88,20 +97,16 @@ def gemm(a, b, c, *, trans_a=False, trans_b=False, epilogue=EPI_BF16, aux=None, 
             raise ValueError("aux must have the shape of c")
         ldaux = _rows2d(aux, "aux")
     prof = PROFILE
+    opts = _gemm_opts(grid_limit, tile, ring)
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if ah or bh or ch:
-        _lib.check(lib.paced_gemm_bf16_heads(_p(a), _p(b), _p(c), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
-                                             int(trans_a), int(trans_b), epilogue, alpha, mask_scale, drop_p, drop_seed, splits,
-                                             ah, bh, ch, _stream()), "paced_gemm_bf16_heads")
-    else:
-        _lib.check(lib.paced_gemm_bf16(_p(a), _p(b), _p(c), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
-                                       int(trans_a), int(trans_b), epilogue, alpha, mask_scale, drop_p, drop_seed, splits,
-                                       _stream()), "paced_gemm_bf16")
+    _lib.check(lib.paced_gemm_bf16_ex(_p(a), _p(b), _p(c), _p(aux), M, N, K, lda, ldb, ldc, ldaux,
+                                      int(trans_a), int(trans_b), epilogue, alpha, mask_scale, drop_p, drop_seed, splits,
+                                      ah, bh, ch, 1, 0, 0, 0, opts, _stream()), "paced_gemm_bf16_ex")
     if prof is not None:
         e1.record()
-        prof.append(((int(trans_a), int(trans_b), int(epilogue), lib.paced_gemm_last_kernel()), 2.0 * M * N * K, e0, e1))
+        prof.append(((int(trans_a), int(trans_b), int(epilogue), opts.kernel), 2.0 * M * N * K, e0, e1))
     return c
 
 
@@ -115,21 +120,23 @@ def sign_bits_buffer(M, N, device):
 
 
 def gemm_batched(a, b, c, *, M, N, K, lda, ldb, ldc, batch, stride_a, stride_b, stride_c, trans_a=False, trans_b=False,
-                 epilogue=EPI_BF16, alpha=1.0, splits=1):
+                 epilogue=EPI_BF16, alpha=1.0, splits=1, grid_limit=None, tile=None, ring=None):
     """``batch`` products of one shape in one launch; member i reads a.data + i*stride_a, b.data + i*stride_b and writes
     c.data + i*stride_c (strides and leading dimensions in elements).  The tensors only provide base pointers and dtypes."""
     lib = _lib.load()
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
     _chk(c, F32 if epilogue in (EPI_F32, EPI_ATOMIC_F32) else BF16, "c")
     prof = PROFILE
+    opts = _gemm_opts(grid_limit, tile, ring)
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(lib.paced_gemm_bf16_batched(_p(a), _p(b), _p(c), M, N, K, lda, ldb, ldc, int(trans_a), int(trans_b), epilogue,
-                                           alpha, splits, batch, stride_a, stride_b, stride_c, _stream()), "paced_gemm_bf16_batched")
+    _lib.check(lib.paced_gemm_bf16_ex(_p(a), _p(b), _p(c), 0, M, N, K, lda, ldb, ldc, 0, int(trans_a), int(trans_b), epilogue,
+                                      alpha, 1.0, 0.0, 0, splits, 0, 0, 0, batch, stride_a, stride_b, stride_c, opts, _stream()),
+               "paced_gemm_bf16_ex (batched)")
     if prof is not None:
         e1.record()
-        prof.append(((int(trans_a), int(trans_b), int(epilogue), lib.paced_gemm_last_kernel()), 2.0 * M * N * K * batch, e0, e1))
+        prof.append(((int(trans_a), int(trans_b), int(epilogue), opts.kernel), 2.0 * M * N * K * batch, e0, e1))
     return c
 
 
@@ -139,8 +146,13 @@ def gemm_set_ring(on: bool):
 
 
 def gemm_set_grid(workgroups: int):
-    """At most that many workgroups per 256x256 phased launch from now on (0 = one per compute unit)."""
+    """Process default: at most that many workgroups per 256x256 phased launch from now on (0 = one per compute unit).
+    For benchmarks and tests; product code passes ``grid_limit=`` per call."""
     _lib.check(_lib.load().paced_gemm_set_grid(int(workgroups)), "paced_gemm_set_grid")
+
+
+def gemm_get_grid() -> int:
+    return int(_lib.load().paced_gemm_get_grid())
 
 
 def gemm_set_tile(tile: int):

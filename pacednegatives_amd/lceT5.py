@@ -285,6 +285,13 @@ class LCEModel:
         self.nograd_grid_layers = int(self.hparams.get("nograd_grid_layers", os.environ.get("PACED_NOGRAD_GRID_LAYERS", "1000")))
         # with overlap_forwards: training_step returns once the numbers it logs are on the host (see there); False = wait for the step
         self.run_ahead = bool(self.hparams.get("run_ahead", os.environ.get("PACED_RUN_AHEAD", "1") != "0"))
+        # memory one step adds at its peak, per batch shape (measured on the first overlapped step of that shape), and
+        # the bytes this process may count on (None: what the device reports free plus what torch already holds)
+        self._step_peak = {}
+        self.memory_limit_bytes = self.hparams.get("memory_limit_bytes", None)
+        if self.memory_limit_bytes is None and os.environ.get("PACED_MEMORY_LIMIT"):
+            self.memory_limit_bytes = int(os.environ["PACED_MEMORY_LIMIT"])
+        self.ran_ahead = False                 # whether the last training_step returned before its backward pass was over
         self._side_stream = self._aux_stream = None
         self._host_vals = None                 # pinned: what a step hands to the host (statistics, eta, mean main loss)
         self.difficulty = float(self.weights.eta.item())
@@ -334,8 +341,19 @@ class LCEModel:
         K.lce_group(pce, nce, ce, int(self.hparams.n), bool(self.hparams.use_mean))
         return ce
 
+    def _two_steps_fit(self, shape_key) -> bool:
+        """Whether two steps' activations of this batch shape can be alive at once (see the end of training_step)."""
+        peak = self._step_peak.get(shape_key)
+        if peak is None:
+            return False
+        limit = self.memory_limit_bytes
+        if limit is None:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            limit = free + torch.cuda.memory_reserved(self.device)
+        return torch.cuda.memory_allocated(self.device) + 2 * peak <= 0.9 * limit
+
     # ---- the step
-    def _forward_pair(self, p, n, save, call, after_encoder=None):
+    def _forward_pair(self, p, n, save, call, after_encoder=None, gemm_grid=0):
         """Run the positive and negative batches; one packed call when their lengths agree."""
         eng = self.model.engine
         # every rank draws its own masks, as the independent RNG streams of DDP ranks do in the reference
@@ -344,10 +362,13 @@ class LCEModel:
         if p["input_ids"].shape[1] == n["input_ids"].shape[1]:
             ids = torch.cat([p["input_ids"].to(self.device), n["input_ids"].to(self.device)], 0)
             lab = torch.cat([p["labels"].to(self.device), n["labels"].to(self.device)], 0)
-            st = eng.forward(ids, lab, save=save, drop_p=self.dropout, seed=seed, after_encoder=after_encoder)
+            st = eng.forward(ids, lab, save=save, drop_p=self.dropout, seed=seed, after_encoder=after_encoder,
+                             gemm_grid=gemm_grid, gemm_grid_layers=self.nograd_grid_layers)
             return [st], st.logits[:2 * B], st.logits[2 * B:]
-        sp = eng.forward(p["input_ids"], p["labels"], save=save, drop_p=self.dropout, seed=seed)
-        sn = eng.forward(n["input_ids"], n["labels"], save=save, drop_p=self.dropout, seed=seed ^ 0x55555555, after_encoder=after_encoder)
+        sp = eng.forward(p["input_ids"], p["labels"], save=save, drop_p=self.dropout, seed=seed,
+                         gemm_grid=gemm_grid, gemm_grid_layers=self.nograd_grid_layers)
+        sn = eng.forward(n["input_ids"], n["labels"], save=save, drop_p=self.dropout, seed=seed ^ 0x55555555, after_encoder=after_encoder,
+                         gemm_grid=gemm_grid, gemm_grid_layers=self.nograd_grid_layers)
         return [sp, sn], sp.logits, sn.logits
 
     def training_step(self, batch, batch_nb):
@@ -372,6 +393,12 @@ class LCEModel:
         # for the same reason.  Values are those of the in-order schedule.  The first step runs in order, so that
         # everything cached on first use exists before two streams read it.
         overlap = self.overlap_forwards and self.global_step > 0 and self.device.type == "cuda"
+        shape_key = (B, nneg, int(p["input_ids"].shape[1]), int(n["input_ids"].shape[1]))
+        measure_peak = overlap and self.run_ahead and shape_key not in self._step_peak
+        if measure_peak:
+            torch.cuda.synchronize(self.device)
+            torch.cuda.reset_peak_memory_stats(self.device)
+            mem_before = torch.cuda.memory_allocated(self.device)
         R = 2 * B
         g_pos = 1.0 / R
         g_neg = (1.0 / R) * ((1.0 / nneg) if use_mean else 1.0)
@@ -381,9 +408,9 @@ class LCEModel:
         if share and self.dropout != 0.0:
             raise ValueError("share_forward needs dropout 0: with dropout on, the reference's two passes draw different masks")
 
-        def no_grad_rows():
+        def no_grad_rows(gemm_grid=0):
             """(a) no-grad forwards and the LCE rows                                        :131-135"""
-            states, plog, nlog = self._forward_pair(p, n, save=False, call=0)
+            states, plog, nlog = self._forward_pair(p, n, save=False, call=0, gemm_grid=gemm_grid)
             pce = torch.empty(2 * B, dtype=F32, device=self.device)
             nce = torch.empty(2 * B * nneg, dtype=F32, device=self.device)
             K.cross_entropy(plog, plab, pce, None, ignore_index=ign)
@@ -451,25 +478,19 @@ class LCEModel:
 
             def start_no_grad_forwards():
                 aux.wait_stream(main)                   # parameters of the last update, and (d)'s encoder forward
-                eng = self.model.engine
-                if self.nograd_grid > 0:
-                    eng.on_encoder_layer = lambda l: K.gemm_set_grid(self.nograd_grid if l < self.nograd_grid_layers else 0)
-                try:
-                    with torch.cuda.stream(aux):
-                        box["loss"] = no_grad_rows()
-                        box["no_grad_done"] = aux.record_event()
-                        # (b) follows (a) on the same stream, as in the reference.  What the host reads of it (the
-                        # statistics, eta after the update) is final here, long before the backward pass is over: the
-                        # copy to pinned memory is enqueued now and only its event is waited for at the end of the step,
-                        # so the host enqueues the next step while the GPU is still in this one's backward pass.
-                        box["weights"], box["stats"] = meta_update(box["loss"])
-                        self._host_vals[0:4].copy_(box["stats"], non_blocking=True)
-                        self._host_vals[4:5].copy_(self.weights.eta, non_blocking=True)
-                        box["meta_read"] = aux.record_event()
-                finally:
-                    eng.on_encoder_layer = None
-                    if self.nograd_grid > 0:
-                        K.gemm_set_grid(0)
+                with torch.cuda.stream(aux):
+                    # the 256x256 products of these forwards leave compute units to the decoder kernels of the main
+                    # stream: a per-call launch option, so no other launch of the process is affected
+                    box["loss"] = no_grad_rows(gemm_grid=max(0, self.nograd_grid))
+                    box["no_grad_done"] = aux.record_event()
+                    # (b) follows (a) on the same stream, as in the reference.  What the host reads of it (the
+                    # statistics, eta after the update) is final here, long before the backward pass is over: the
+                    # copy to pinned memory is enqueued now and only its event is waited for at the end of the step,
+                    # so the host enqueues the next step while the GPU is still in this one's backward pass.
+                    box["weights"], box["stats"] = meta_update(box["loss"])
+                    self._host_vals[0:4].copy_(box["stats"], non_blocking=True)
+                    self._host_vals[4:5].copy_(self.weights.eta, non_blocking=True)
+                    box["meta_read"] = aux.record_event()
 
             def read_main_loss(rows):
                 self._host_vals[5:6].copy_(rows.mean().view(1), non_blocking=True)
@@ -518,9 +539,17 @@ class LCEModel:
             # meet blocks of this step that other streams have not released yet (the backward's operands, handed to the
             # weight-gradient stream), so two steps' activations can be alive at once: where that does not fit the
             # GPU's memory the allocator would stall and re-allocate every step, and the host waits for the whole step.
-            if (not self.run_ahead or
-                    2 * torch.cuda.max_memory_allocated(self.device) > 0.85 * torch.cuda.get_device_properties(self.device).total_memory):
+            # The rule compares twice ONE step's peak (measured on the first overlapped step of this batch shape, which
+            # waits for the whole step) plus what is allocated between steps with the memory this process can count on:
+            # what the device reports free (other processes' share is gone from it) plus what torch already holds.
+            if measure_peak:
                 main.synchronize()
+                self._step_peak[shape_key] = max(0, torch.cuda.max_memory_allocated(self.device) - mem_before)
+                self.ran_ahead = False
+            else:
+                self.ran_ahead = self.run_ahead and self._two_steps_fit(shape_key)
+                if not self.ran_ahead:
+                    main.synchronize()
             box["meta_read"].synchronize()
             box["main_read"].synchronize()
             host = self._host_vals[0:6].tolist()

@@ -92,7 +92,18 @@ def grad_scale() -> float:
 
 
 def shard_indices(n_items: int, rank_: int, world: int):
-    """Items of rank r under a non-shuffling distributed sampler: r, r+W, ... (tail dropped so that every
-    rank sees the same number of items)."""
-    usable = n_items - n_items % world
-    return list(range(rank_, usable, world))
+    """Items of rank r under ``torch.utils.data.DistributedSampler(shuffle=False, drop_last=False)``, the sampler Lightning
+    puts in front of the reference's sequential DataLoader when ``strategy='ddp'`` (``train/train_lce.py:89-91``,
+    ``lceT5.py:66-67``): the index list 0 .. n-1 is padded with its own head up to a multiple of the world size, then rank r
+    takes positions r, r+W, ...  Every rank sees ceil(n / W) items; with n % W != 0 the first items are seen twice."""
+    if world <= 1:
+        return list(range(n_items))
+    if n_items == 0:
+        return []
+    per_rank = -(-n_items // world)
+    order = list(range(n_items))
+    pad = per_rank * world - n_items
+    while pad > 0:                       # (a list shorter than the padding is repeated, as the sampler does)
+        order += order[:pad]
+        pad = per_rank * world - len(order)
+    return order[rank_:per_rank * world:world]

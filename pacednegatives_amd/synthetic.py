@@ -45,8 +45,12 @@ def write_synthetic_dataset(out_dir: str, n_records: int, n_neg: int, seed: int 
         negs = rng.sample(range(n_neg * 4), n_neg)
         recs.append({"query_id": f"q{i}", "doc_id_a": f"d{n_neg * 4 + i}", "doc_id_b": [f"d{j}" for j in negs]})
     path = os.path.join(out_dir, "synthetic.json")
-    with open(path, "w") as f:
+    # written under a private name and moved into place: several rank processes may write the (identical) file at once,
+    # and none must ever read a half-written one
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
         json.dump(recs, f)
+    os.replace(tmp, path)
     return path, ListCorpus(docs, queries)
 
 

@@ -131,7 +131,6 @@ class T5Engine:
         self._bucket_cache: Dict[int, torch.Tensor] = {}
         self.force_kv_projection = False      # tests: take the explicit K/V projection path of the cross-attention
         self.dw_stream = None                  # when set: weight-gradient products of backward() run on this stream
-        self.on_encoder_layer = None           # when set: called with the layer index before each encoder layer of forward() is enqueued
         self.ffn_bit_mask = os.environ.get("PACED_FFN_BITMASK", "1") != "0"   # encoder FFN backward masks by saved sign bits
         self.head_major = os.environ.get("PACED_HEAD_MAJOR", "1") != "0"   # encoder attention operands head-major (see forward)
         self._bucket_dec = torch.tensor([0, 1], dtype=torch.int32, device=self.device)   # offsets 0 and -1 (HF:244-249)
@@ -199,9 +198,12 @@ class T5Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids: torch.Tensor, labels: torch.Tensor, *, save: bool, drop_p: float = 0.0, seed: int = 0,
-                want_logits: bool = True, after_encoder=None) -> ForwardState:
+                want_logits: bool = True, after_encoder=None, gemm_grid: int = 0, gemm_grid_layers: int = 1000) -> ForwardState:
         """``after_encoder`` (optional callable) runs once the encoder's kernels are enqueued, before the decoder's
-        small kernels: the place to start independent work on another stream."""
+        small kernels: the place to start independent work on another stream.  ``gemm_grid`` > 0: the 256x256 products of
+        this call (of its encoder layers below ``gemm_grid_layers``, its decoder and its LM head) are launched with at
+        most that many workgroups, leaving the other compute units to kernels of other streams (a per-call option of the
+        library: nothing else launched meanwhile is affected)."""
         dims, P = self.dims, self.params
         if input_ids.dim() != 2 or labels.dim() != 2 or labels.shape[1] != 2 or labels.shape[0] != input_ids.shape[0]:
             raise ValueError(f"expected input_ids [N,S] and labels [N,2], got {tuple(input_ids.shape)} and {tuple(labels.shape)}")
@@ -231,8 +233,7 @@ class T5Engine:
         for l in range(dims.num_layers):
             pre = f"enc.{l}."
             sv = _EncLayerSaved()
-            if self.on_encoder_layer is not None:
-                self.on_encoder_layer(l)
+            grid = gemm_grid if (gemm_grid > 0 and l < gemm_grid_layers) else None
             xn, rstd1 = self._empty(M, d), torch.empty(M, dtype=F32, device=self.device)
             K.rmsnorm_fwd(h, P.w(pre + "ln1"), xn, rstd1, eps=dims.eps)
             # The attention's operands are head-major ([heads, M, 64]; the products write and read that layout): a
@@ -241,21 +242,21 @@ class T5Engine:
                 qkv, ctx = self._heads(3 * H, M), self._heads(H, M)
             else:
                 qkv, ctx = self._empty(M, 3 * I), self._empty(M, I)
-            K.gemm(xn, P.w(pre + "qkv"), qkv)
+            K.gemm(xn, P.w(pre + "qkv"), qkv, grid_limit=grid)
             q_, k_, v_ = self._split_qkv(qkv, H)
             lse = torch.empty(N * H * S, dtype=F32, device=self.device)
             K.enc_attn_fwd(q_, k_, v_, ctx, lse, st.bias_tbl, N, S, H,
                            drop_p=p, drop_seed=self._seed(st, _SITE_ATT, l))
             h_mid = self._empty(M, d)
-            K.gemm(ctx, P.w(pre + "o"), h_mid, epilogue=K.EPI_RES_DROP, aux=h, drop_p=p, drop_seed=self._seed(st, _SITE_ATT_OUT, l))
+            K.gemm(ctx, P.w(pre + "o"), h_mid, epilogue=K.EPI_RES_DROP, aux=h, drop_p=p, drop_seed=self._seed(st, _SITE_ATT_OUT, l), grid_limit=grid)
             xn2, rstd2 = self._empty(M, d), torch.empty(M, dtype=F32, device=self.device)
             K.rmsnorm_fwd(h_mid, P.w(pre + "ln2"), xn2, rstd2, eps=dims.eps)
             act = self._empty(M, ff)
             # the backward only needs to know which activations survived relu and dropout: one bit each
             actbits = K.sign_bits_buffer(M, ff, self.device) if save and self.ffn_bit_mask and ff % 8 == 0 else None
-            K.gemm(xn2, P.w(pre + "wi"), act, epilogue=K.EPI_RELU_DROP, aux=actbits, drop_p=p, drop_seed=self._seed(st, _SITE_FF_ACT, l))
+            K.gemm(xn2, P.w(pre + "wi"), act, epilogue=K.EPI_RELU_DROP, aux=actbits, drop_p=p, drop_seed=self._seed(st, _SITE_FF_ACT, l), grid_limit=grid)
             h_out = self._empty(M, d)
-            K.gemm(act, P.w(pre + "wo"), h_out, epilogue=K.EPI_RES_DROP, aux=h_mid, drop_p=p, drop_seed=self._seed(st, _SITE_FF_OUT, l))
+            K.gemm(act, P.w(pre + "wo"), h_out, epilogue=K.EPI_RES_DROP, aux=h_mid, drop_p=p, drop_seed=self._seed(st, _SITE_FF_OUT, l), grid_limit=grid)
             if save:
                 sv.h_in, sv.xn, sv.rstd1, sv.qkv, sv.ctx, sv.lse = h, xn, rstd1, qkv, ctx, lse
                 sv.h_mid, sv.xn2, sv.rstd2, sv.act, sv.actbits = h_mid, xn2, rstd2, act, actbits
@@ -331,7 +332,7 @@ class T5Engine:
             st.g_last, st.rstd_df = g, rstd_df
         if want_logits:
             st.logits = torch.empty(Md, dims.vocab_size, dtype=F32, device=self.device)
-            K.gemm(y, P.w("shared"), st.logits, epilogue=K.EPI_F32)
+            K.gemm(y, P.w("shared"), st.logits, epilogue=K.EPI_F32, grid_limit=gemm_grid if gemm_grid > 0 else None)
         if not save:
             st.enc_out = None
         return st

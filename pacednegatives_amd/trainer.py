@@ -74,6 +74,11 @@ class Trainer:
 
     def fit(self, model, datamodule):
         rank, world, _local = init_distributed()
+        devices = self.devices if isinstance(self.devices, int) else len(self.devices) if isinstance(self.devices, (list, tuple)) else None
+        if devices is not None and devices != world:
+            # Lightning starts `devices` processes by itself; here they come from torchrun or pacednegatives_amd.launcher
+            raise RuntimeError(f"Trainer(devices={self.devices}) but {world} rank process(es) are running: launch one process per "
+                               "device (train/train_lce.py --num_gpus N does; or python -m torch.distributed.run --nproc-per-node N)")
         if getattr(datamodule, "dataset", None) is None:
             datamodule.setup()
         self.train_dataloader = datamodule.train_dataloader(rank=rank, world_size=world)

@@ -45,7 +45,7 @@ def test_lce_weights_kernel_vs_reference_fixture(golden_dir, ei):
     np.testing.assert_allclose(lw.eta_grad[0].item(), g[f"w_grad{ei}"][0], rtol=1e-6)
 
 
-@pytest.mark.parametrize("ci,n", [(0, 2), (1, 4), (2, 16)])
+@pytest.mark.parametrize("ci,n", [(0, 2), (1, 4), (2, 16), (3, 32)])
 @pytest.mark.parametrize("use_mean", [False, True])
 def test_pair_loss_kernels_vs_reference_fixture(golden_dir, ci, n, use_mean):
     """pacednegatives/lceT5.py:116-123 with the caller's view (:134): fp32 logits recorded with the rows the reference's
@@ -197,6 +197,74 @@ def test_k8_s128_b64_shape_properties():
     model = _model(n=8)
     rows = model.pair_loss(full[:64], full[64:].view(-1, 8, 32128), pos["labels"], neg["labels"])
     within("K=8,S=128,B=64 LCE rows vs torch grouping of the same logits (rel.)", rel_rows(rows.cpu(), want.cpu()), 2e-6)
+
+
+def test_t5_large_k32_shard_properties_and_the_run_ahead_rule():
+    """configs[4]'s per-GPU shard at full size: t5-large (24 + 24 layers, d 1024, 16 heads, d_ff 4096), K = 32 negatives,
+    seq_len 256, 32 tuples = 1056 sequences = 270336 token rows per pass, the eta curriculum's meta step on.  The oracle
+    cannot run this size, so size-independent properties: a sequence's logits in the batch equal those of the same
+    sequence alone (to rounding: big and small tiles sum in different orders); the LCE rows (the view by n = 32 of
+    lceT5.py:134,151) equal torch's grouping of the per-token losses of the same logits; with the learning rates at zero
+    and dropout off, step 1 (three streams, no-grad products on 7/8 of the units) reproduces step 0 (one stream) bit for
+    bit; and two steps' activations do not fit the GPU beside each other, so from the step after the one that measures a
+    step's peak the host must wait for the whole step instead of running ahead."""
+    from pacednegatives_amd.synthetic import token_batch
+    model = _model(model_name="t5-large", eta=0.3466, n=32, batch_size=32, lr=0.0, meta_lr=0.0, total_steps=100, warmup_steps=0)
+    V = model.model.config.vocab_size
+    pos, neg = token_batch(32, 32, 256, V, seed=91, device="cuda")
+    outs = [model.training_step((pos, neg), i) for i in range(4)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o["loss_rows"], outs[0]["loss_rows"]) and torch.equal(o["main_loss_rows"], outs[0]["main_loss_rows"])
+        assert torch.equal(o["weights"], outs[0]["weights"])
+    assert torch.equal(outs[0]["loss_rows"], outs[0]["main_loss_rows"])        # dropout off: both passes see the same weights
+    assert outs[0]["loss_rows"].shape == (64,) and torch.isfinite(outs[0]["loss_rows"]).all()
+    # step 0 ran in order, step 1 measured one step's peak (and waited), steps 2 and 3 applied the rule
+    (key, peak), = model._step_peak.items()
+    total = torch.cuda.get_device_properties(0).total_memory
+    print(f"t5-large K=32 shard: one step adds {peak / 2**30:.1f} GiB at its peak; device {total / 2**30:.0f} GiB")
+    assert key == (32, 32, 256, 256) and 2 * peak > total, "this shard was chosen because two steps do not fit"
+    assert model.ran_ahead is False
+    eng = model.model.engine
+    ids = torch.cat([pos["input_ids"], neg["input_ids"]], 0)
+    labels = torch.cat([pos["labels"], neg["labels"]], 0)
+    full = eng.forward(ids, labels, save=False, drop_p=0.0, seed=1).logits.view(1056, 2, V)
+    worst = 0.0
+    for i in (0, 31, 32, 500, 1055):
+        one = eng.forward(ids[i:i + 1], labels[i:i + 1], save=False, drop_p=0.0, seed=1).logits.view(1, 2, V)
+        worst = max(worst, relerr(full[i:i + 1].cpu(), one.cpu()))
+    within("t5-large K=32 S=256: a sequence in the batch vs alone (rel. to max |logit|)", worst, B_LOGITS_EMU)
+    ce = torch.nn.functional.cross_entropy(full.view(-1, V).float(), labels.cuda().view(-1), reduction="none")
+    want = ce[:64] + ce[64:].view(-1, 32).sum(1)
+    rows = model.pair_loss(full[:32], full[32:].view(-1, 32, V), pos["labels"], neg["labels"])
+    within("t5-large K=32 LCE rows vs torch grouping of the same logits (rel.)", rel_rows(rows.cpu(), want.cpu()), 2e-6)
+    within("t5-large K=32 step rows vs rows of a plain forward (rel.)", rel_rows(outs[0]["loss_rows"].cpu(), want.cpu()), 2e-6)
+
+
+@pytest.mark.parametrize("limit,expect", [(1 << 50, True), (1 << 20, False)])
+def test_run_ahead_rule_takes_both_branches(limit, expect):
+    """The host returns from a step before its backward pass is over only if two steps' activations fit the memory the
+    process can count on (``memory_limit_bytes`` stands in for it here).  Either way the steps are the same."""
+    from pacednegatives_amd.synthetic import token_batch
+    model = _model(eta=5.0, n=2, batch_size=4, memory_limit_bytes=limit)
+    ref = _model(eta=5.0, n=2, batch_size=4, run_ahead=False)
+    batch = token_batch(4, 2, 40, model.model.config.vocab_size, seed=5, device="cuda")
+    flags = []
+    for i in range(4):
+        a, b = model.training_step(batch, i), ref.training_step(batch, i)
+        flags.append(model.ran_ahead)
+        assert ref.ran_ahead is False
+        assert torch.equal(a["loss_rows"], b["loss_rows"]) and torch.equal(a["main_loss_rows"], b["main_loss_rows"])
+    torch.cuda.synchronize()
+    assert flags == [False, False, expect, expect]        # in order; measuring step; then the rule
+    assert len(model._step_peak) == 1 and next(iter(model._step_peak.values())) > 0
+    # another batch shape is measured on its own
+    batch2 = token_batch(4, 2, 56, model.model.config.vocab_size, seed=6, device="cuda")
+    model.training_step(batch2, 4)
+    assert model.ran_ahead is False and len(model._step_peak) == 2
+    model.training_step(batch2, 5)
+    assert model.ran_ahead is expect
+    torch.cuda.synchronize()
 
 
 def test_monot5_factory_scores_a_tokenised_batch():

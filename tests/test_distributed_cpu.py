@@ -72,10 +72,58 @@ def test_two_rank_gloo_training_loop(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     res = [json.load(open(tmp_path / f"result{r}.json")) for r in range(2)]
-    # 11 records over 2 ranks: 5 each (tail dropped), rank r holds r, r+2, ...
-    assert res[0]["items"] == [0, 2, 4, 6, 8] and res[1]["items"] == [1, 3, 5, 7, 9]
-    assert res[0]["batches"] == res[1]["batches"] == [2, 2, 1]
+    # 11 records over 2 ranks: padded with item 0 to 12 (torch's DistributedSampler rule), 6 each, rank r holds r, r+2, ...
+    assert res[0]["items"] == [0, 2, 4, 6, 8, 10] and res[1]["items"] == [1, 3, 5, 7, 9, 0]
+    assert res[0]["batches"] == res[1]["batches"] == [2, 2, 2]
     # every rank ends on the same eta (mean of the two local updates each step), and the callback fed it to the sampler
     assert abs(res[0]["eta"] - res[1]["eta"]) < 1e-12
     assert abs(res[0]["eta"] - (0.3 + 3 * 0.15)) < 1e-6
     assert res[0]["paces"] == res[1]["paces"] and abs(res[0]["paces"][1] - 0.45) < 1e-6
+
+
+@pytest.mark.parametrize("n,world", [(11, 2), (23, 2), (16, 8), (17, 8), (3, 8), (1, 4), (100, 3), (0, 2)])
+def test_shard_indices_equal_torchs_distributed_sampler(n, world):
+    """The rule Lightning's ddp strategy applies to the reference's sequential loader: DistributedSampler(shuffle=False)."""
+    from torch.utils.data import DistributedSampler
+    from pacednegatives_amd import parallel
+    for r in range(world):
+        want = list(DistributedSampler(range(n), num_replicas=world, rank=r, shuffle=False)) if n else []
+        assert parallel.shard_indices(n, r, world) == want, (n, world, r)
+
+
+def test_trainer_refuses_a_device_count_that_is_not_the_world_size():
+    from pacednegatives_amd.trainer import Trainer
+    t = Trainer(devices=2, max_epochs=1)
+    with pytest.raises(RuntimeError, match="rank process"):
+        t.fit(object(), object())
+
+
+LAUNCHED = r"""
+import os, sys
+r = int(os.environ["RANK"])
+assert os.environ["WORLD_SIZE"] == "3" and os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+print("{" + f'"rank": {r}, "port": {os.environ["MASTER_PORT"]}' + "}")
+print("noise from rank", r)
+mode = sys.argv[1]
+if mode == "fail" and r == 1:
+    sys.exit(7)
+if mode == "hang" or (mode == "fail" and r != 1):
+    import time; time.sleep(60)
+"""
+
+
+def test_launcher_starts_ranks_relays_rank0_and_reports_failures(tmp_path, capfd):
+    """pacednegatives_amd.launcher (what train/train_lce.py --num_gpus N and bench.py --gpus N use when no torchrun
+    environment is present): ranks get the torchrun variables, rank 0's stdout is relayed, a failing rank stops the
+    others with a non-zero code, and a hung run is stopped at the time limit with code 124."""
+    import time
+    from pacednegatives_amd import launcher
+    script = tmp_path / "ranked.py"
+    script.write_text(LAUNCHED)
+    assert launcher.launch_ranks(3, [sys.executable, str(script), "ok"], json_only_stdout=True) == 0
+    out, err = capfd.readouterr()
+    assert out.strip().startswith('{"rank": 0') and "noise" not in out and "noise from rank 0" in err
+    t0 = time.time()
+    assert launcher.launch_ranks(3, [sys.executable, str(script), "fail"]) == 1
+    assert launcher.launch_ranks(3, [sys.executable, str(script), "hang"], timeout_s=2.0) == 124
+    assert time.time() - t0 < 40

@@ -140,7 +140,9 @@ def test_batch_loader_shards_like_the_distributed_sampler(dataset):
     for rank in (0, 1):
         part = [p["input_ids"] for p, _ in dm.train_dataloader(rank=rank, world_size=2)]
         got = torch.cat([torch.nn.functional.pad(t, (0, 200 - t.shape[1])) for t in part])
-        assert torch.equal(got, rows[rank:22:2])      # 23 items: the odd one out is dropped so that ranks stay in step
+        # 23 items: padded with item 0 to 24, as the non-shuffling DistributedSampler does, so that ranks stay in step
+        want = torch.cat([rows, rows[:1]])[rank::2]
+        assert torch.equal(got, want)
 
 
 class _Trainer:

@@ -123,6 +123,61 @@ def test_gemm_grid_limit_gives_the_same_product(limit):
     assert torch.equal(g, A.float().t() @ A.float())
     with pytest.raises(RuntimeError):
         K.gemm_set_grid(-1)
+    # the same limit and tile as options of the call: same bits, and the process defaults are left alone
+    assert K.gemm_get_grid() == 0
+    c2 = torch.full((M, N), float("nan"), device=DEV)
+    K.gemm(A, B, c2, epilogue=K.EPI_F32, grid_limit=limit, tile=256)
+    g2 = torch.zeros(Kc, Kc, device=DEV)
+    K.gemm(A[:, :Kc], A[:, :Kc], g2, trans_a=True, trans_b=True, epilogue=K.EPI_ATOMIC_F32, splits=0, grid_limit=limit, tile=256)
+    torch.cuda.synchronize()
+    assert torch.equal(c2, want) and torch.equal(g2, g)
+    assert K.gemm_get_grid() == 0
+    K.gemm_set_grid(7)
+    try:
+        assert K.gemm_get_grid() == 7
+        K.gemm(A, B, c2, epilogue=K.EPI_F32, grid_limit=0, tile=128)       # an explicit 0 overrides the default of 7
+        torch.cuda.synchronize()
+        assert torch.equal(c2, want)
+        assert K.gemm_get_grid() == 7                                       # a call's options never touch the default
+    finally:
+        K.gemm_set_grid(0)
+
+
+def test_gemm_entry_points_without_options_equal_the_one_with():
+    """paced_gemm_bf16 / _heads / _batched (no per-call options) against paced_gemm_bf16_ex, which the wrappers use."""
+    lib = K._lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    M, N, Kc = 300, 256, 192
+    A, B = bf(rnd((M, Kc), 70)), bf(rnd((N, Kc), 71))
+    res = bf(rnd((M, N), 72))
+    want = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    K.gemm(A, B, want, epilogue=K.EPI_RES_DROP, aux=res, drop_p=0.2, drop_seed=9)
+    got = torch.empty_like(want)
+    K._lib.check(lib.paced_gemm_bf16(A.data_ptr(), B.data_ptr(), got.data_ptr(), res.data_ptr(), M, N, Kc, Kc, Kc, N, N, 0, 0,
+                                     K.EPI_RES_DROP, 1.0, 1.0, 0.2, 9, 1, st))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # head-major output
+    N2 = 256
+    wanth = torch.zeros(N2 // 64, M, 64, device=DEV, dtype=torch.bfloat16)
+    K.gemm(A, B, wanth)
+    goth = torch.zeros_like(wanth)
+    K._lib.check(lib.paced_gemm_bf16_heads(A.data_ptr(), B.data_ptr(), goth.data_ptr(), 0, M, N2, Kc, Kc, Kc, 64, 0, 0, 0,
+                                           K.EPI_BF16, 1.0, 1.0, 0.0, 0, 1, 0, 0, wanth.stride(0), st))
+    torch.cuda.synchronize()
+    assert torch.equal(goth, wanth)
+    # batched: 3 members of [64, 64] x [64, 64]^T
+    a3, b3 = bf(rnd((3 * 64, 64), 73)), bf(rnd((3 * 64, 64), 74))
+    want3 = torch.empty(3 * 64, 64, device=DEV, dtype=torch.bfloat16)
+    K.gemm_batched(a3, b3, want3, M=64, N=64, K=64, lda=64, ldb=64, ldc=64, batch=3, stride_a=4096, stride_b=4096, stride_c=4096)
+    got3 = torch.empty_like(want3)
+    K._lib.check(lib.paced_gemm_bf16_batched(a3.data_ptr(), b3.data_ptr(), got3.data_ptr(), 64, 64, 64, 64, 64, 64, 0, 0, K.EPI_BF16, 1.0, 1,
+                                             3, 4096, 4096, 4096, st))
+    torch.cuda.synchronize()
+    assert torch.equal(got3, want3)
+    opts = K._lib.GemmOpts(-1, 999, -1, 0)
+    assert lib.paced_gemm_bf16_ex(A.data_ptr(), B.data_ptr(), got.data_ptr(), 0, M, N, Kc, Kc, Kc, N, 0, 0, 0, K.EPI_BF16, 1.0, 1.0, 0.0, 0, 1,
+                                  0, 0, 0, 1, 0, 0, 0, opts, st) != 0 and b"tile" in lib.paced_last_error()
 
 
 def test_gemm_batched_per_head_products(tile):
@@ -484,7 +539,9 @@ def _ref_attention(q, k, v, bias, N, S, H, mask=None):
     return o, lse
 
 
-@pytest.mark.parametrize("N,S,H", [(2, 16, 2), (1, 100, 3), (3, 128, 2), (2, 256, 12), (1, 333, 1)])
+# (S = 384, 512: the dK/dV kernel asks for more than 64 KB of LDS -- 39168 + 72 S bytes from S = 367 -- and needs the
+# opt-in attribute; S = 600: beyond 512 tokens the bias-gradient sums share one LDS array through atomics)
+@pytest.mark.parametrize("N,S,H", [(2, 16, 2), (1, 100, 3), (3, 128, 2), (2, 256, 12), (1, 333, 1), (1, 384, 2), (2, 512, 2), (1, 600, 1)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_enc_attention_fwd_bwd(N, S, H, p):
     I = H * 64
@@ -583,7 +640,7 @@ def test_gemm_weight_gradient_with_a_head_major_operand(T, O, Iin, which):
     assert (got - want).abs().max().item() <= 2e-3 * want.abs().max().item()
 
 
-@pytest.mark.parametrize("N,S,H", [(2, 16, 2), (1, 100, 3), (2, 256, 12), (1, 333, 1)])
+@pytest.mark.parametrize("N,S,H", [(2, 16, 2), (1, 100, 3), (2, 256, 12), (1, 333, 1), (1, 384, 2), (2, 512, 2), (1, 600, 1)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 @pytest.mark.parametrize("what", ["qkv", "all"])
 def test_enc_attention_head_major_operands_give_the_same_bits(N, S, H, p, what):

@@ -73,7 +73,7 @@ def test_lce_weights_known_answer():
     np.testing.assert_allclose(eta.grad.numpy(), [-0.15625], rtol=1e-6)
 
 
-@pytest.mark.parametrize("ci,n", [(0, 2), (1, 4), (2, 16)])
+@pytest.mark.parametrize("ci,n", [(0, 2), (1, 4), (2, 16), (3, 32)])
 def test_pair_loss(golden_dir, ci, n):
     g = load(golden_dir, "weights_loss.npz")
     pl, nl = torch.from_numpy(g[f"l_pl{ci}"]), torch.from_numpy(g[f"l_nl{ci}"])

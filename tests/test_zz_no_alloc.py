@@ -25,16 +25,22 @@ def test_static_selection_equals_the_workspace_one_twice_in_a_row():
     assert 16 << 20 < lib.paced_pool_topk_static_bytes() < 32 << 20
     # first call: the limits themselves, enough rows for several chunks of the static sweep (32768 rows each);
     # second call: fewer queries, smaller k, a pool shorter than the first chunk of the first call's lists
+    # warm-up: module load and the per-device symbol lookup happen on the first call; after it, a call must leave the
+    # device's free memory (hipMemGetInfo: sees any hipMalloc, torch's or the library's) where it found it
+    wq, wp = _case(2, 100, 64, 4, 3, True)
+    K.pool_topk_static(wq, wp, 4, torch.empty(2, 4, device="cuda"), torch.empty(2, 4, dtype=torch.int64, device="cuda"))
+    torch.cuda.synchronize()
     for (Q, Np, D, k, integer, base) in ((64, 150_000, 128, 1024, True, 0), (5, 3000, 64, 37, True, 1000), (17, 70_000, 256, 300, False, 7)):
         qry, pool = _case(Q, Np, D, k, 11 + Q, integer)
         want_s, want_i = K.pool_topk(qry, pool, k, index_base=base)
         got_s = torch.full((Q, k), float("nan"), device="cuda")
         got_i = torch.full((Q, k), -7, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
-        before = torch.cuda.memory_allocated()
+        before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
         K.pool_topk_static(qry, pool, k, got_s, got_i, index_base=base)
         assert torch.cuda.memory_allocated() == before
         torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before, "the device's free memory changed across the call"
         assert torch.equal(got_i, want_i), (Q, Np, k)
         assert torch.equal(got_s, want_s), (Q, Np, k)
         assert int(got_i.min()) >= base

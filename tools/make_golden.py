@@ -116,7 +116,7 @@ def golden_weights_and_loss(ref):
         out[f"w_grad{ei}"] = w.eta.grad.numpy().copy()
         out[f"w_eta{ei}"] = np.array([eta], np.float32)
     V, T = 64, 2
-    for ci, (B, n) in enumerate(((4, 2), (4, 4), (2, 16))):
+    for ci, (B, n) in enumerate(((4, 2), (4, 4), (2, 16), (2, 32))):      # (2, 32): K = 32 negatives, the t5-large configuration
         pl = torch.randn(B, T, V, generator=g)
         nl = torch.randn(B * n, T, V, generator=g)
         op = torch.tensor([[7, 1]] * B)
@@ -273,9 +273,14 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
     ref = import_reference_lcet5()
-    golden_sampler()
-    golden_weights_and_loss(ref)
-    golden_t5(ref)
-    golden_mining()
+    only = set(sys.argv[1:])          # e.g. `make_golden.py weights_loss` regenerates that file alone
+    if not only or "sampler" in only:
+        golden_sampler()
+    if not only or "weights_loss" in only:
+        golden_weights_and_loss(ref)
+    if not only or "t5" in only:
+        golden_t5(ref)
+    if not only or "mining" in only:
+        golden_mining()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

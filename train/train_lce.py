@@ -7,8 +7,11 @@ same sequence (model, data module, trainer with ChangeDifficulty, fit, save to o
 names cannot be downloaded here) and ``--synthetic N`` (build an N-record synthetic corpus and
 negatives file in out_dir instead of reading ``--data`` / ``--dataset_name``).
 
-Multi-GPU: launch one process per GPU, e.g.
+Multi-GPU: ``--num_gpus N`` alone is enough, as for the reference (whose Lightning trainer starts one process per
+device, ``train_lce.py:89-94``): run without a torchrun environment, the script starts N rank processes of itself
+before it touches the GPU, relays rank 0's output and exits with a non-zero code if a rank fails.  Under
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train/train_lce.py ... --num_gpus 8
+it joins the ranks it is given; a WORLD_SIZE that differs from --num_gpus is an error.
 """
 import argparse
 import logging
@@ -31,7 +34,10 @@ def main(data: str, dataset_name: str, out_dir: str, total_steps: int = 100000, 
     from pacednegatives_amd import synthetic as syn
 
     os.makedirs(out_dir, exist_ok=True)
-    init_distributed()
+    _rank, world, _local = init_distributed()
+    if world != max(1, int(num_gpus)):
+        raise RuntimeError(f"--num_gpus {num_gpus} but this run has {world} rank process(es): start the script without a "
+                           "torchrun environment (it launches its own ranks) or with --nproc-per-node equal to --num_gpus")
     args = {
         "model_name": model_name,
         "total_steps": total_steps // batch_size,
@@ -102,4 +108,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if not a.synthetic and not (a.data and a.dataset_name):
         ap.error("--data and --dataset_name are required unless --synthetic N is given")
+    from pacednegatives_amd import launcher
+    if a.num_gpus > 1 and not launcher.under_launcher():
+        # one process per device, as Lightning's ddp strategy gives the reference; this process makes no GPU call
+        raise SystemExit(launcher.launch_ranks(a.num_gpus))
     main(**vars(a))
