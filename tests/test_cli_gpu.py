@@ -88,6 +88,8 @@ def test_num_gpus_flag_starts_that_many_ranks(tmp_path):
     recs = _metrics(out_self)
     assert [m["step"] for m in recs] == [1, 2, 3]
     out_run = str(tmp_path / "torchrun")
+    # (torch.distributed.run parses the script's arguments too and takes "--n" for an abbreviation of its own options)
+    args = ["--n_neg" if a == "--n" else a for a in args]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29617", CLI, "--out_dir", out_run, "--num_gpus", "2"] + args, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)

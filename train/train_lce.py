@@ -11,7 +11,8 @@ Multi-GPU: ``--num_gpus N`` alone is enough, as for the reference (whose Lightni
 device, ``train_lce.py:89-94``): run without a torchrun environment, the script starts N rank processes of itself
 before it touches the GPU, relays rank 0's output and exits with a non-zero code if a rank fails.  Under
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train/train_lce.py ... --num_gpus 8
-it joins the ranks it is given; a WORLD_SIZE that differs from --num_gpus is an error.
+it joins the ranks it is given; a WORLD_SIZE that differs from --num_gpus is an error.  (torch.distributed.run rejects
+the reference's ``--n`` flag as an ambiguous abbreviation of its own options: spell it ``--n_neg`` there.)
 """
 import argparse
 import logging
@@ -92,7 +93,9 @@ if __name__ == "__main__":
     ap.add_argument("--lr", type=float, default=0.001)
     ap.add_argument("--meta_lr", type=float, default=None)
     ap.add_argument("--var", type=float, default=0.01)
-    ap.add_argument("--n", type=int, default=2)
+    # (--n_neg: the same flag under a name torch.distributed.run's own parser accepts -- it reads every argument of the
+    # command line, the script's included, and rejects "--n" as an ambiguous abbreviation of --nnodes / --nproc-per-node / ...)
+    ap.add_argument("--n", "--n_neg", dest="n", type=int, default=2)
     ap.add_argument("--use_max", type=_bool, nargs="?", const=True, default=False)
     ap.add_argument("--warmup_steps", type=int, default=10000)
     ap.add_argument("--sample", type=_bool, nargs="?", const=True, default=False)
