@@ -139,16 +139,40 @@ def position_bias(table: torch.Tensor, q_len: int, k_len: int, bidirectional: bo
     return table[b].permute(2, 0, 1).unsqueeze(0)
 
 
+# Storage points at which the HIP path holds a bf16 value (names accepted by ``t5_forward(keep_fp32=...)``):
+#   params      every weight (the bf16 shadow the kernels read)
+#   enc_stream  the encoder's residual stream (embedding output and both residual sums of every layer)
+#   enc_norm    the encoder's normalised rows, the final norm included (= the encoder output)
+#   enc_qkv     q, k, v of the encoder
+#   enc_probs   un-normalised attention probabilities fed to the PV product
+#   enc_ctx     attention context
+#   enc_act     feed-forward activations
+#   dec_stream, dec_norm, dec_qkv, dec_probs, dec_ctx, dec_act   the same for the decoder's two-token rows (q/k/v and
+#               context of its cross-attention included)
+#   head_in     the rescaled final decoder norm that feeds the LM head
+ROUNDING_POINTS = ("params", "enc_stream", "enc_norm", "enc_qkv", "enc_probs", "enc_ctx", "enc_act",
+                   "dec_stream", "dec_norm", "dec_qkv", "dec_probs", "dec_ctx", "dec_act", "head_in")
+
+
 class _R:
-    """Rounding policy: identity in fp32 mode, round-trip through bf16 when emulating."""
+    """Rounding policy: identity in fp32 mode, round-trip through bf16 when emulating, except at the storage points
+    named in ``keep`` (for experiments that ask what each point contributes to the error)."""
 
-    def __init__(self, emulate: bool):
+    def __init__(self, emulate: bool, keep=()):
         self.emulate = emulate
+        self.keep = frozenset(keep)
+        unknown = self.keep - set(ROUNDING_POINTS)
+        if unknown:
+            raise ValueError(f"unknown storage points {sorted(unknown)}")
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        if not self.emulate:
+    def __call__(self, x: torch.Tensor, point: str = None) -> torch.Tensor:
+        if not self.emulate or (point is not None and point in self.keep):
             return x
         return x.to(torch.bfloat16).to(torch.float32)
+
+    def at(self, point: str):
+        """The policy bound to one storage point (what ``attention`` receives for its probabilities)."""
+        return lambda x: self(x, point)
 
 
 def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
@@ -188,19 +212,28 @@ def _lin(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 
 def t5_forward(params: Dict[str, torch.Tensor], dims: T5Dims, input_ids: torch.Tensor, labels: torch.Tensor,
-               emulate_bf16: bool = False, return_internals: bool = False, drop=None):
+               emulate_bf16: bool = False, return_internals: bool = False, drop=None, keep_fp32=(), relu_mask=None):
     """Logits [N, T, V] (fp32) of ``T5ForConditionalGeneration(input_ids, labels)`` with dropout 0, or with
     caller-supplied dropout masks: ``drop(site, layer, dec, shape)`` returns the factor tensor (0 or 1/(1-p)) of
     that shape for the dropout sites of HF modeling_t5.py - "emb" (:725), "final" (:745), "att" (:168, on the
     probabilities, shape [N,H,T,S]), "att_out" (:400), "ff_act" (:86), "ff_out" (:140), "catt" / "catt_out"
     (:168 / :431 of the cross-attention) - so that a test can replay the masks another implementation used.
+    ``relu_mask(layer, dec, shape)`` (optional) returns a 0/1 tensor, or None, that REPLACES the ReLU's own decision
+    for that feed-forward layer (a = pre-activation * mask, gradient passes where mask = 1): a unit whose
+    pre-activation is a rounding error away from zero can fall on either side in two implementations, and replaying
+    the other implementation's decisions takes that discontinuity out of a gradient comparison.
+    ``keep_fp32``: storage points (``ROUNDING_POINTS``) NOT rounded to bf16 under ``emulate_bf16``.
 
     Structure: HF:663-750 (stack), HF:392-400/304-367 (self-attention sub-layer), HF:138-140/84-93
     (feed-forward sub-layer), HF:459-498 (decoder block), HF:618-637 (shift right), HF:1044-1047
     (tied-head rescale + lm_head).  No attention mask on the encoder (reference drops it), causal
     mask on decoder self-attention, zero bias on cross-attention (HF:337-342)."""
-    r = _R(emulate_bf16)
-    P = {k: r(v) for k, v in params.items()} if emulate_bf16 else params
+    r = _R(emulate_bf16, keep_fp32)
+    P = {k: r(v, "params") for k, v in params.items()} if emulate_bf16 else params
+
+    def relu(layer, dec, x):
+        m = None if relu_mask is None else relu_mask(layer, dec, tuple(x.shape))
+        return torch.relu(x) if m is None else x * m
     H, dk, eps = dims.num_heads, dims.d_kv, dims.eps
     internals = {}
 
@@ -212,23 +245,24 @@ def t5_forward(params: Dict[str, torch.Tensor], dims: T5Dims, input_ids: torch.T
     N = input_ids.shape[0]
 
     # ---- encoder
-    h = r(dm("emb", 0, False, P["shared.weight"][input_ids]))  # [N,S,d]
+    h = r(dm("emb", 0, False, P["shared.weight"][input_ids]), "enc_stream")  # [N,S,d]
     S = input_ids.shape[1]
     enc_bias = position_bias(P["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], S, S, True, dims)
     for l in range(dims.num_layers):
         p = f"encoder.block.{l}.layer."
-        xn = r(rms_norm(h, P[p + "0.layer_norm.weight"], eps))
-        q = r(_lin(xn, P[p + "0.SelfAttention.q.weight"]))
-        k = r(_lin(xn, P[p + "0.SelfAttention.k.weight"]))
-        v = r(_lin(xn, P[p + "0.SelfAttention.v.weight"]))
-        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), enc_bias, False, r, pm("att", l, False, N, S, S)))
-        h = r(h + dm("att_out", l, False, _lin(ctx, P[p + "0.SelfAttention.o.weight"])))
-        xn = r(rms_norm(h, P[p + "1.layer_norm.weight"], eps))
-        a = r(dm("ff_act", l, False, torch.relu(_lin(xn, P[p + "1.DenseReluDense.wi.weight"]))))
-        h = r(h + dm("ff_out", l, False, _lin(a, P[p + "1.DenseReluDense.wo.weight"])))
+        xn = r(rms_norm(h, P[p + "0.layer_norm.weight"], eps), "enc_norm")
+        q = r(_lin(xn, P[p + "0.SelfAttention.q.weight"]), "enc_qkv")
+        k = r(_lin(xn, P[p + "0.SelfAttention.k.weight"]), "enc_qkv")
+        v = r(_lin(xn, P[p + "0.SelfAttention.v.weight"]), "enc_qkv")
+        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), enc_bias, False, r.at("enc_probs"),
+                          pm("att", l, False, N, S, S)), "enc_ctx")
+        h = r(h + dm("att_out", l, False, _lin(ctx, P[p + "0.SelfAttention.o.weight"])), "enc_stream")
+        xn = r(rms_norm(h, P[p + "1.layer_norm.weight"], eps), "enc_norm")
+        a = r(dm("ff_act", l, False, relu(l, False, _lin(xn, P[p + "1.DenseReluDense.wi.weight"]))), "enc_act")
+        h = r(h + dm("ff_out", l, False, _lin(a, P[p + "1.DenseReluDense.wo.weight"])), "enc_stream")
         if return_internals:
             internals[f"enc{l}"] = h
-    enc = r(dm("final", 0, False, rms_norm(h, P["encoder.final_layer_norm.weight"], eps)))
+    enc = r(dm("final", 0, False, rms_norm(h, P["encoder.final_layer_norm.weight"], eps)), "enc_norm")
     if return_internals:
         internals["enc_out"] = enc
 
@@ -237,29 +271,31 @@ def t5_forward(params: Dict[str, torch.Tensor], dims: T5Dims, input_ids: torch.T
     dec_ids[:, 1:] = labels[:, :-1]
     dec_ids = dec_ids.masked_fill(dec_ids == -100, 0)
     T = dec_ids.shape[1]
-    h = r(dm("emb", 0, True, P["shared.weight"][dec_ids]))
+    h = r(dm("emb", 0, True, P["shared.weight"][dec_ids]), "dec_stream")
     dec_bias = position_bias(P["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], T, T, False, dims)
     for l in range(dims.num_decoder_layers):
         p = f"decoder.block.{l}.layer."
-        xn = r(rms_norm(h, P[p + "0.layer_norm.weight"], eps))
-        q = r(_lin(xn, P[p + "0.SelfAttention.q.weight"]))
-        k = r(_lin(xn, P[p + "0.SelfAttention.k.weight"]))
-        v = r(_lin(xn, P[p + "0.SelfAttention.v.weight"]))
-        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), dec_bias, True, r, pm("att", l, True, N, T, T)))
-        h = r(h + dm("att_out", l, True, _lin(ctx, P[p + "0.SelfAttention.o.weight"])))
-        xn = r(rms_norm(h, P[p + "1.layer_norm.weight"], eps))
-        q = r(_lin(xn, P[p + "1.EncDecAttention.q.weight"]))
-        k = r(_lin(enc, P[p + "1.EncDecAttention.k.weight"]))
-        v = r(_lin(enc, P[p + "1.EncDecAttention.v.weight"]))
-        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), None, False, r, pm("catt", l, True, N, T, S)))
-        h = r(h + dm("catt_out", l, True, _lin(ctx, P[p + "1.EncDecAttention.o.weight"])))
-        xn = r(rms_norm(h, P[p + "2.layer_norm.weight"], eps))
-        a = r(dm("ff_act", l, True, torch.relu(_lin(xn, P[p + "2.DenseReluDense.wi.weight"]))))
-        h = r(h + dm("ff_out", l, True, _lin(a, P[p + "2.DenseReluDense.wo.weight"])))
+        xn = r(rms_norm(h, P[p + "0.layer_norm.weight"], eps), "dec_norm")
+        q = r(_lin(xn, P[p + "0.SelfAttention.q.weight"]), "dec_qkv")
+        k = r(_lin(xn, P[p + "0.SelfAttention.k.weight"]), "dec_qkv")
+        v = r(_lin(xn, P[p + "0.SelfAttention.v.weight"]), "dec_qkv")
+        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), dec_bias, True, r.at("dec_probs"),
+                          pm("att", l, True, N, T, T)), "dec_ctx")
+        h = r(h + dm("att_out", l, True, _lin(ctx, P[p + "0.SelfAttention.o.weight"])), "dec_stream")
+        xn = r(rms_norm(h, P[p + "1.layer_norm.weight"], eps), "dec_norm")
+        q = r(_lin(xn, P[p + "1.EncDecAttention.q.weight"]), "dec_qkv")
+        k = r(_lin(enc, P[p + "1.EncDecAttention.k.weight"]), "dec_qkv")
+        v = r(_lin(enc, P[p + "1.EncDecAttention.v.weight"]), "dec_qkv")
+        ctx = r(attention(_heads(q, H, dk), _heads(k, H, dk), _heads(v, H, dk), None, False, r.at("dec_probs"),
+                          pm("catt", l, True, N, T, S)), "dec_ctx")
+        h = r(h + dm("catt_out", l, True, _lin(ctx, P[p + "1.EncDecAttention.o.weight"])), "dec_stream")
+        xn = r(rms_norm(h, P[p + "2.layer_norm.weight"], eps), "dec_norm")
+        a = r(dm("ff_act", l, True, relu(l, True, _lin(xn, P[p + "2.DenseReluDense.wi.weight"]))), "dec_act")
+        h = r(h + dm("ff_out", l, True, _lin(a, P[p + "2.DenseReluDense.wo.weight"])), "dec_stream")
         if return_internals:
             internals[f"dec{l}"] = h
     y = dm("final", 0, True, rms_norm(h, P["decoder.final_layer_norm.weight"], eps))
-    y = r(y * (dims.d_model ** -0.5))                          # HF:1044-1045 (tied embeddings)
+    y = r(y * (dims.d_model ** -0.5), "head_in")               # HF:1044-1045 (tied embeddings)
     logits = _lin(y, P["shared.weight"])                       # HF:1047
     if return_internals:
         return logits, internals

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import lce_ref  # noqa: E402
 from oracle.t5_ref import T5Dims as RefDims, init_params, t5_forward  # noqa: E402
-from test_engine_gpu import B_LOGITS_EMU, B_ROWS_EMU, rel_rows, relerr, within  # noqa: E402
+from test_engine_gpu import B_GRAD_REPLAY, B_LOGITS_EMU, B_ROWS_EMU, rel_rows, relerr, relu_replay, within  # noqa: E402
 
 
 # t5-large at full depth (24 + 24 layers): bounds of the full-size property test below, ~2x the values measured on an MI355X
@@ -80,12 +80,12 @@ def _engine(dims_args, seed):
     return m, P, rd
 
 
-def _fwd_bwd_vs_oracle(m, P, rd, ids, labels, tag, grad_bound=5e-2):
+def _fwd_bwd_vs_oracle(m, P, rd, ids, labels, tag, grad_bound=B_GRAD_REPLAY):
     from pacednegatives_amd import kernels as K
     N, V = ids.shape[0], rd.vocab_size
     st = m.engine.forward(ids, labels, save=True, drop_p=0.0, seed=1)
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    lg = t5_forward(leaves, rd, ids, labels, emulate_bf16=True)
+    lg = t5_forward(leaves, rd, ids, labels, emulate_bf16=True, relu_mask=relu_replay(st))
     within(f"{tag} logits vs bf16-emulating oracle", relerr(st.logits.cpu().view_as(lg), lg.detach()), B_LOGITS_EMU)
     loss = torch.empty(N * 2, device="cuda")
     dl = torch.empty(N * 2, V, device="cuda", dtype=torch.bfloat16)
@@ -101,7 +101,7 @@ def _fwd_bwd_vs_oracle(m, P, rd, ids, labels, tag, grad_bound=5e-2):
         l2 = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
         worst = max(worst, l2)
         assert l2 < (8e-2 if int((want != 0).sum()) < 64 else grad_bound), (k, l2)
-    within(f"{tag} worst per-tensor gradient L2 error", worst, grad_bound)
+    within(f"{tag} worst per-tensor gradient L2 error (ReLU decisions replayed)", worst, grad_bound)
     return st
 
 

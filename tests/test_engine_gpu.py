@@ -23,6 +23,17 @@ from pacednegatives_amd.config import NAMED  # noqa: E402
 B_LOGITS_EMU, B_LOGITS_HF = 6e-3, 1e-2          # logits, relative to the largest logit      (measured 4.9e-3, 4.6e-3)
 B_LOSS_EMU, B_LOSS_HF = 2e-3, 3e-3              # per-token losses, relative                 (measured 9.2e-4, 1.6e-3)
 B_ROWS_EMU, B_ROWS_HF = 2.5e-3, 5e-3            # LCE rows of training steps 0-2, relative    (measured 1.4e-3, 2.3e-3; step 0: 3e-4)
+# per-tensor relative L2 error of the gradients with the engine's ReLU decisions replayed in the oracle (see relu_replay)
+# (measured 1.16e-2 .. 1.36e-2 over the tiny, t5-small/base/large-width cases; with the oracle taking its own decisions 2.9e-2 .. 4.5e-2
+#  without dropout and up to 9.1e-2 with it.  Dropout on, three seeds: worst tensor 1.56e-2 .. 1.84e-2, median 8.0e-3 .. 8.7e-3.)
+B_GRAD_REPLAY = 2.5e-2
+B_GRAD_REPLAY_DROP, B_GRAD_REPLAY_DROP_MEDIAN = 3.5e-2, 1.7e-2
+# What the stated tolerance "logits/loss within 1e-3 bf16" holds for: the loss the step consumes, i.e. the LCE rows of a first
+# step (same parameters on both sides) against the oracle that rounds where the kernels round (measured 3e-4) and against the
+# fp32 fixture recorded from the reference's own pair_loss (6e-4).  The per-token losses sit AT that figure (9.2e-4 and 1.02e-3
+# on the two fixture batches; bound B_LOSS_EMU).  It does NOT hold for the logits: rounding the weights to bf16 alone moves them
+# by 3.5e-3 of the largest logit at t5-base depth (tools/rounding_points.py), before any activation is stored.
+B_STATED = 1e-3
 TINY = NAMED["t5-tiny"]
 RTINY = RefDims(TINY.vocab_size, TINY.d_model, TINY.d_kv, TINY.num_heads, TINY.d_ff, TINY.num_layers, TINY.num_decoder_layers)
 
@@ -44,6 +55,23 @@ def rel_rows(got, want):
     """max over elements of |got - want| / |want| (per-row losses are far from zero)"""
     got, want = torch.as_tensor(got).double(), torch.as_tensor(want).double()
     return ((got - want).abs() / want.abs().clamp_min(1e-12)).max().item()
+
+
+def relu_replay(st):
+    """``relu_mask`` hook for ``oracle.t5_ref.t5_forward`` that replays the engine's ReLU decisions of the forward state
+    ``st`` (call before ``engine.backward``, which releases the saved activations): a unit is on where the engine's
+    stored feed-forward activation is positive.  (With dropout on, a dropped unit reads as off; its output and its
+    gradient are zero either way.)  A unit whose pre-activation lies within rounding of zero can fall on either side
+    in the two implementations and then switches a whole row of a weight gradient on or off; replaying the decisions
+    takes that discontinuity out of a gradient comparison."""
+    masks = {}
+    for dec, layers in ((False, st.enc_layers), (True, st.dec_layers)):
+        for l, sv in enumerate(layers):
+            masks[(l, dec)] = (sv.act > 0).float().cpu()
+
+    def relu_mask(layer, dec, shape):
+        return masks[(layer, dec)].view(shape)
+    return relu_mask
 
 
 def make_model(seed=0):
@@ -113,6 +141,7 @@ def test_backward_gradients_vs_oracle(S):
     labels = torch.tensor([[6136, 1]] * B)
     st = m.engine.forward(ids, labels, save=True, drop_p=0.0, seed=1)
     from pacednegatives_amd import kernels as K
+    replay = relu_replay(st)
     loss = torch.empty(B * 2, device="cuda")
     dl = torch.empty(B * 2, TINY.vocab_size, device="cuda", dtype=torch.bfloat16)
     K.cross_entropy(st.logits, labels.cuda().view(-1).contiguous(), loss, dl, gscale=1.0 / (B * 2))
@@ -121,8 +150,17 @@ def test_backward_gradients_vs_oracle(S):
     torch.cuda.synchronize()
     got = {k: v.cpu() for k, v in m.params.to_hf("grad").items()}
 
+    # what the un-replayed comparison measures (the oracle takes its own ReLU decisions): printed to show the size of the
+    # flip effect, bounded as before
+    free = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lf = t5_forward(free, RTINY, ids, labels, emulate_bf16=True)
+    torch.nn.functional.cross_entropy(lf.view(-1, lf.shape[-1]), labels.view(-1), reduction="mean").backward()
+    worst_free = max(((got[k] - (v.grad if v.grad is not None else torch.zeros_like(v))).norm() /
+                      ((v.grad if v.grad is not None else torch.zeros_like(v)).norm() + 1e-12)).item() for k, v in free.items())
+    within(f"S={S} worst per-tensor gradient L2 error, oracle with its OWN ReLU decisions", worst_free, 8e-2)
+
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    lg = t5_forward(leaves, RTINY, ids, labels, emulate_bf16=True)
+    lg = t5_forward(leaves, RTINY, ids, labels, emulate_bf16=True, relu_mask=replay)
     torch.nn.functional.cross_entropy(lg.view(-1, lg.shape[-1]), labels.view(-1), reduction="mean").backward()
     worst = worst_q = worst_far = 0.0
     for k, v in leaves.items():
@@ -146,7 +184,7 @@ def test_backward_gradients_vs_oracle(S):
         far = int(((got[k] - want).abs() > 0.1 * denom).sum())
         worst_far = max(worst_far, far / want.numel())
         assert far <= max(2, 1e-3 * want.numel()), (k, far, want.numel())
-    within(f"S={S} worst per-tensor gradient L2 error", worst, 5e-2)
+    within(f"S={S} worst per-tensor gradient L2 error (ReLU decisions replayed)", worst, B_GRAD_REPLAY)
     within(f"S={S} worst 99.9th-percentile element error", worst_q, 0.1)
     print(f"MEASURED S={S} worst fraction of far-off entries: {worst_far:.2e}")
     assert worst > 0
@@ -171,7 +209,7 @@ def test_forward_backward_at_real_widths(d, H, ff):
     st = m.engine.forward(ids, labels, save=True, drop_p=0.0, seed=1)
     assert st.cross2
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    lg = t5_forward(leaves, rd, ids, labels, emulate_bf16=True)
+    lg = t5_forward(leaves, rd, ids, labels, emulate_bf16=True, relu_mask=relu_replay(st))
     within(f"d={d} logits vs bf16-emulating oracle", relerr(st.logits.cpu().view_as(lg), lg.detach()), B_LOGITS_EMU)
     loss = torch.empty(B * 2, device="cuda")
     dl = torch.empty(B * 2, 6400, device="cuda", dtype=torch.bfloat16)
@@ -186,8 +224,8 @@ def test_forward_backward_at_real_widths(d, H, ff):
         want = v.grad if v.grad is not None else torch.zeros_like(v)
         l2 = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
         worst = max(worst, l2)
-        assert l2 < (8e-2 if int((want != 0).sum()) < 64 else 5e-2), (k, l2)
-    within(f"d={d} worst per-tensor gradient L2 error", worst, 5e-2)
+        assert l2 < (8e-2 if int((want != 0).sum()) < 64 else B_GRAD_REPLAY), (k, l2)
+    within(f"d={d} worst per-tensor gradient L2 error (ReLU decisions replayed)", worst, B_GRAD_REPLAY)
 
 
 def test_tile_ordered_sign_bits_give_the_same_gradients(monkeypatch):
@@ -270,9 +308,11 @@ def test_dropout_masks_replayed_in_the_oracle(seed):
         return mk(math.prod(shape)).view(shape)    # hidden states: token row x feature
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    lg = t5_forward(leaves, RTINY, ids, labels, emulate_bf16=True, drop=drop)
+    lg = t5_forward(leaves, RTINY, ids, labels, emulate_bf16=True, drop=drop, relu_mask=relu_replay(st))
     scale = lg.abs().max().item()
-    within("dropout on: logits vs oracle replaying the masks", relerr(st.logits.cpu().view_as(lg), lg.detach()), B_LOGITS_EMU)
+    with torch.no_grad():          # the logits are compared with the oracle taking its own ReLU decisions, as everywhere else
+        lg_own = t5_forward(P, RTINY, ids, labels, emulate_bf16=True, drop=drop)
+    within("dropout on: logits vs oracle replaying the masks", relerr(st.logits.cpu().view_as(lg_own), lg_own), B_LOGITS_EMU)
     # with the masks of another seed the logits differ far more than that: the comparison is not vacuous
     st2 = m.engine.forward(ids, labels, save=False, drop_p=p, seed=seed + 1)
     assert (st2.logits.cpu().view_as(lg) - lg.detach()).abs().max().item() > 5e-2 * scale
@@ -289,8 +329,8 @@ def test_dropout_masks_replayed_in_the_oracle(seed):
         want = v.grad if v.grad is not None else torch.zeros_like(v)
         errs[k] = ((got[k] - want).norm() / (want.norm() + 1e-12)).item()
     worst = max(errs, key=errs.get)
-    within(f"dropout on, seed {seed}: worst per-tensor gradient L2 error ({worst})", errs[worst], 1.2e-1)
-    within(f"dropout on, seed {seed}: median per-tensor gradient L2 error", sorted(errs.values())[len(errs) // 2], 6e-2)
+    within(f"dropout on, seed {seed}: worst per-tensor gradient L2 error ({worst}), ReLU decisions replayed", errs[worst], B_GRAD_REPLAY_DROP)
+    within(f"dropout on, seed {seed}: median per-tensor gradient L2 error", sorted(errs.values())[len(errs) // 2], B_GRAD_REPLAY_DROP_MEDIAN)
 
 
 def test_cross_attention_paths_agree():
@@ -355,6 +395,8 @@ def test_training_steps_vs_oracle_and_reference_fixture(golden_dir, use_mean):
         within(f"step {it} LCE rows vs reference fixture, fp32 (rel.)", rel_rows(rows, g[tag + f"loss{it}"]), B_ROWS_HF)
         if it == 0:
             np.testing.assert_allclose(model.difficulty, float(g[tag + "eta0"][0]), rtol=1e-5)
+            within("step 0 LCE rows vs bf16-emulating oracle (rel.): the stated 1e-3", rel_rows(rows, ref["loss"]), B_STATED)
+            within("step 0 LCE rows vs reference fixture, fp32 (rel.): the stated 1e-3", rel_rows(rows, g[tag + "loss0"]), B_STATED)
     w = model.model.params.master("enc.0.qkv")[:TINY.inner].cpu()
     w_ref = P["encoder.block.0.layer.0.SelfAttention.q.weight"]
     # updates 1 and 2 have size ~0.5*lr and ~lr (warm-up); a gradient entry whose sign differs between
