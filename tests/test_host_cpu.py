@@ -31,7 +31,23 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in include/paced_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
-    assert _lib.load().paced_abi_version() == 3
+    assert _lib.load().paced_abi_version() == _lib.EXPECTED_ABI == 4
+
+
+def test_a_library_of_another_abi_version_is_refused(tmp_path, monkeypatch):
+    """Argument lists changed between ABI versions: a build that exports every symbol but reports another version must be
+    refused at load, not called with shifted arguments."""
+    import subprocess
+    from pacednegatives_amd import _lib
+    names = declared_symbols()
+    src = tmp_path / "old.c"
+    src.write_text("".join(f"int {n}(void) {{ return 0; }}\n" for n in names if n != "paced_abi_version") + "int paced_abi_version(void) { return 3; }\n")
+    so = tmp_path / "libold.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)])
+    monkeypatch.setattr(_lib, "LIB_PATH", str(so))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.PacedHipError, match="ABI version 3.*expects 4"):
+        _lib.load()
 
 
 def test_product_never_imports_the_oracle():
