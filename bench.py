@@ -36,6 +36,38 @@ BF16_DENSE_PEAK = 2.5e15     # FLOP/s, MI355X dense bf16 MFMA
 HBM_PEAK = 8.0e12            # B/s
 
 
+TRAFFIC_STEP = "profiles/r3_pmc_traffic.json"            # tools/measure_r3.sh: two --pmc passes of `bench.py --steps 1 --warmup 0`
+TRAFFIC_MINING = "profiles/r3_pmc_traffic_mining.json"   # ... of tools/mine_once.py
+
+
+def committed_traffic(rel_path, keys, applies):
+    """(bytes, source) from a committed counter summary: the value is a constant of the repository, not a measurement of
+    this run, and `source` says which file and for which kernel sources it was taken (their digest is stored in the file
+    by tools/pmc_summary.py; when the kernels have changed since, the value is withheld)."""
+    path = os.path.join(ROOT, rel_path)
+    if not applies or not os.path.exists(path):
+        return None, None
+    try:
+        doc = json.load(open(path))
+        value = doc[keys[0]][keys[1]]
+    except Exception:
+        return None, None
+    want, have = doc.get("kernel_sources_sha256"), kernel_sources_digest()
+    if want is not None and want != have:
+        return None, f"{rel_path} was taken with other kernel sources ({want[:12]} != {have[:12]}): withheld"
+    return value, f"committed profile {rel_path} (rocprofv3 --pmc, separate passes; kernel sources {have[:12]}), not this run"
+
+
+def kernel_sources_digest():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pacednegatives_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def t5_forward_flops(dims, S, T=2):
     """Algorithmic FLOPs of one sequence's forward (2 per MAC; GEMMs, attention products, LM head)."""
     d, I, ff, V = dims.d_model, dims.inner, dims.d_ff, dims.vocab_size
@@ -79,6 +111,7 @@ def run_train(args, rank, world, device):
     # one instrumented step: per-launch HIP events around the contraction kernel
     roof = None
     K.PROFILE = []
+    was_overlapped = bool(model.overlap_forwards)
     model.overlap_forwards = False      # per-launch durations: no second stream sharing the GPU with the timed kernel
     model.training_step(batch, args.warmup + args.steps)
     torch.cuda.synchronize()
@@ -88,13 +121,10 @@ def run_train(args, rank, world, device):
         ms = e0.elapsed_time(e1)
         s = by_sym.setdefault(key, [0.0, 0.0, 0])
         s[0] += flops; s[1] += ms * 1e-3; s[2] += 1
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")      # rocprofv3 --pmc passes of this same command
-    if os.path.exists(tpath) and (args.model, B, nneg, S) == ("t5-base", 32, 16, 256):
-        try:
-            traffic = json.load(open(tpath))["gemm_phased_kernel"]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    # HBM-side counters cannot be collected inside this run (rocprofv3 --pmc wraps the whole process): `traffic` quotes the
+    # committed summary of two --pmc passes of this same command, and says so; null for any other workload
+    traffic, traffic_source = committed_traffic(TRAFFIC_STEP, ("gemm_phased_kernel", "hbm_bytes_per_launch"),
+                                                (args.model, B, nneg, S) == ("t5-base", 32, 16, 256))
 
     def pooled(items):
         f, t, n = (sum(v[i] for _, v in items) for i in range(3))
@@ -108,7 +138,8 @@ def run_train(args, rank, world, device):
         dom = max(phased, key=lambda kv: kv[1][1])
         roof = {"bound": "mfma", "kernel": "gemm_phased_kernel (every launch of one training step)", "achieved": tot_f / tot_t / 1e12,
                 "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s", "frac": tot_f / tot_t / BF16_DENSE_PEAK, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes; profiles/r2_pmc_traffic.json)",
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)",
+                "traffic_source": traffic_source,
                 "flops_per_launch": tot_f / tot_n, "launches": tot_n, "avg_launch_us": tot_t / tot_n * 1e6,
                 "largest_share_variant": {"trans_a,trans_b,epilogue": list(dom[0][:3]), "TFLOP/s": dom[1][0] / dom[1][1] / 1e12,
                                     "launches": dom[1][2], "avg_launch_us": dom[1][1] / dom[1][2] * 1e6},
@@ -128,6 +159,9 @@ def run_train(args, rank, world, device):
                                f"{B} tuples per GPU (global batch {B * world}), dropout {args.dropout}, "
                                "reference-faithful 4 forwards + backward + 2 AdamW",
                    "parallelism": f"dp{world}", "global_batch": B * world, "seq_len": S},
+        "ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                  "backend": dist.get_backend() if dist.is_initialized() else None,
+                  "early_update": bool(model.early_update), "overlap_forwards": was_overlapped},
         "roofline": roof,
         "step_mfma_frac": tuples_per_s * flops_per_tuple / (world * BF16_DENSE_PEAK),
         "algorithmic_flops_per_tuple": flops_per_tuple,
@@ -136,32 +170,45 @@ def run_train(args, rank, world, device):
 
 
 def cpu_baseline(args, dims):
-    """Oracle (fp32 CPU restatement of the reference step) on a bounded sample: 1 tuple of the same shape."""
+    """Oracle (fp32 CPU restatement of the reference step) on a bounded sample of the same workload: B=2 tuples of the same
+    shape on every core the job may use, and the same step at ONE thread on a tuple cut to 1+1 sequences (a step's cost is
+    linear in its sequences: nothing but the loss couples them), scaled to 1+K."""
     from oracle import lce_ref
     from oracle.t5_ref import T5Dims as RefDims, init_params
     from pacednegatives_amd.synthetic import token_batch
     rd = RefDims(dims.vocab_size, dims.d_model, dims.d_kv, dims.num_heads, dims.d_ff, dims.num_layers, dims.num_decoder_layers)
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+
+    def timed(B, n_neg, n_threads, max_steps, warm, budget_s):
+        torch.set_num_threads(n_threads)
+        P = init_params(rd, 0)
+        eta = torch.tensor([0.3466])
+        opt, meta = lce_ref.HFAdamW(P, 1e-3), lce_ref.HFAdamW({"eta": eta}, 1e-3)
+        p, n = token_batch(B, n_neg, args.seq, dims.vocab_size, seed=1234)
+        steps, used = 0, 0.0
+        for i in range(warm + max_steps):
+            t0 = time.perf_counter()
+            lce_ref.training_step(P, rd, eta, opt, meta, i, p["input_ids"], p["labels"], n["input_ids"], n["labels"], n_neg,
+                                  False, 10000, 100000)
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                used += dt; steps += 1
+            if used > budget_s:
+                break
+        return steps, used
+
+    B = args.cpu_batch
+    steps, used = timed(B, args.n_neg, threads, args.cpu_steps, 1, 25.0)
+    out = {"value": B * steps / used, "unit": "triples/s", "cores": threads, "kind": "port",
+           "sample": f"{steps} timed steps (after 1 warm-up) of B={B} tuples (1+{args.n_neg} sequences x {args.seq} tokens each), "
+                     f"{args.model} dims, fp32, dropout 0, torch CPU"}
+    if args.cpu_one_thread:
+        s1, u1 = timed(1, 1, 1, 1, 0, 0.0)
+        out["one_thread"] = {"value": s1 / u1 * 2.0 / (1 + args.n_neg), "unit": "triples/s", "cores": 1,
+                             "sample": f"1 step (no warm-up) of 1 tuple cut to 1+1 sequences x {args.seq} tokens, {u1:.1f} s, "
+                                       f"scaled by 2/(1+{args.n_neg}) to whole tuples"}
     torch.set_num_threads(threads)
-    B = 1
-    P = init_params(rd, 0)
-    eta = torch.tensor([0.3466])
-    opt, meta = lce_ref.HFAdamW(P, 1e-3), lce_ref.HFAdamW({"eta": eta}, 1e-3)
-    p, n = token_batch(B, args.n_neg, args.seq, dims.vocab_size, seed=1234)
-    steps = 0
-    t_used = 0.0
-    for i in range(1 + args.cpu_steps):
-        t0 = time.perf_counter()
-        lce_ref.training_step(P, rd, eta, opt, meta, i, p["input_ids"], p["labels"], n["input_ids"], n["labels"], args.n_neg,
-                              False, 10000, 100000)
-        dt = time.perf_counter() - t0
-        if i > 0:
-            t_used += dt; steps += 1
-        if t_used > 25.0:
-            break
-    return {"value": B * steps / t_used, "unit": "triples/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} timed steps (after 1 warm-up) of B=1 tuple (1+{args.n_neg} sequences x {args.seq} tokens), "
-                      f"{args.model} dims, fp32, dropout 0, torch CPU"}
+    return out
 
 
 def cpu_baseline_mining(pool_rows, queries, k, budget_s=20.0):
@@ -218,13 +265,8 @@ def run_mining(args, rank, world, device):
     total_rows = Np * world
     flops = 2.0 * Q * total_rows * D
     bytes_alg = total_rows * D * 2 + Q * D * 2 + Q * k * 12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic_mining.json")     # rocprofv3 --pmc passes of tools/mine_once.py
-    if os.path.exists(tpath) and (Q, total_rows, k, world) == (4096, 10_000_000, 1000, 1):
-        try:
-            traffic = json.load(open(tpath))["sweep"]["hbm_bytes_per_sweep"]
-        except Exception:
-            traffic = None
+    traffic, traffic_source = committed_traffic(TRAFFIC_MINING, ("sweep", "hbm_bytes_per_sweep"),
+                                                (Q, total_rows, k, world) == (4096, 10_000_000, 1000, 1))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_mining(pool[:min(Np, 1_000_000)], queries, k)
@@ -234,7 +276,7 @@ def run_mining(args, rank, world, device):
             "config": {"workload": f"top-{k} of {Q} queries x {total_rows} pool rows x {D} dims, bf16, pool sharded over {world} GPU(s)"},
             "roofline": {"bound": "mfma", "achieved": flops / el / 1e12, "peak": BF16_DENSE_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": flops / el / (world * BF16_DENSE_PEAK), "hbm_frac": bytes_alg / el / (world * HBM_PEAK),
-                         "algorithmic_bytes": bytes_alg, "traffic": traffic,
+                         "algorithmic_bytes": bytes_alg, "traffic": traffic, "traffic_source": traffic_source,
                          "binding": f"mfma: {Q} FLOP per pool byte against a ridge of {BF16_DENSE_PEAK / HBM_PEAK:.0f}; "
                                     "HBM binds below that many queries per pass"}}
     if cpu is not None:
@@ -254,6 +296,8 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", dest="cpu_steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", dest="cpu_batch", type=int, default=2, help="tuples per step of the CPU baseline")
+    ap.add_argument("--no-cpu-one-thread", dest="cpu_one_thread", action="store_false", help="skip the 1-thread CPU figure")
     ap.add_argument("--skip-mining", action="store_true")
     ap.add_argument("--mine_pool", type=int, default=10_000_000)
     ap.add_argument("--mine_queries", type=int, default=4096)

@@ -501,6 +501,53 @@ def test_dropout_mask_equals_the_numpy_restatement(p, seed):
     assert abs(keep.mean() - (1 - p)) < 4 * math.sqrt(p * (1 - p) / n)
 
 
+def test_dropout_statistics_over_the_sites_and_steps_of_a_run():
+    """The masks the training step actually draws: seeds are derived per (step, call, site, layer) as T5Engine does, and a
+    mask is a pure function of (seed, element index).  On 2^22 elements per mask at p = 0.1: the keep rate of every site,
+    of every residue of the index modulo 4 and modulo 768 blocks; the correlation of the decisions of two sites at the
+    same indices, of two consecutive steps at one site, and of neighbouring elements of one mask.  ~200 z scores are
+    taken; a function without structure keeps them below ~4."""
+    from pacednegatives_amd import t5_engine as E
+    n, p = 1 << 22, 0.1
+    thresh = int(p * 65536 + 0.5)
+    keep_p = 1.0 - thresh / 65536.0
+    sig_rate = math.sqrt(keep_p * (1 - keep_p) / n)
+    sites = (E._SITE_EMB, E._SITE_ATT, E._SITE_ATT_OUT, E._SITE_FF_ACT, E._SITE_FF_OUT, E._SITE_CATT, E._SITE_CATT_OUT)
+
+    def mask(step_seed, site, layer, dec=False):
+        seed = E._mix(step_seed, site + 16 * layer + (4096 if dec else 0))
+        return (K.dropout_mask(n, drop_p=p, drop_seed=seed) > 0).float()
+
+    worst = {"rate": 0.0, "residue": 0.0, "cross-site": 0.0, "cross-step": 0.0, "neighbours": 0.0}
+    base = 0x1234ABCD
+    masks = {}
+    for site in sites:
+        for layer in (0, 5, 11):
+            m = mask(base, site, layer)
+            masks[(site, layer)] = m
+            worst["rate"] = max(worst["rate"], abs(m.mean().item() - keep_p) / sig_rate)
+            r4 = m.view(-1, 4).mean(0)
+            worst["residue"] = max(worst["residue"], ((r4 - keep_p).abs().max().item()) / (sig_rate * 2))
+    var = keep_p * (1 - keep_p)
+    sig_corr = 1.0 / math.sqrt(n)
+
+    def corr(a, b):
+        return (((a - keep_p) * (b - keep_p)).mean().item() / var) / sig_corr
+
+    keys = list(masks)
+    for i in range(0, len(keys) - 1):
+        worst["cross-site"] = max(worst["cross-site"], abs(corr(masks[keys[i]], masks[keys[i + 1]])))
+    for site in (E._SITE_ATT, E._SITE_FF_ACT):
+        a = masks[(site, 0)]
+        for step in (1, 2, 8):             # training_step adds 8 per step to the step seed, the call id below that
+            worst["cross-step"] = max(worst["cross-step"], abs(corr(a, mask(base + step, site, 0))))
+        for d in (1, 2, 3, 4, 5, 64, 768, 3072):
+            worst["neighbours"] = max(worst["neighbours"], abs(corr(a[:-d], a[d:])))
+    print("MEASURED dropout statistics, largest |z| per family:", {k: round(v, 2) for k, v in worst.items()})
+    for k, v in worst.items():
+        assert v < 5.0, (k, v)
+
+
 def test_embedding_fwd_bwd():
     V, d, M = 1000, 128, 777
     table = bf(rnd((V, d), 30))

@@ -36,6 +36,14 @@ out = {"sweep": {"hbm_bytes_per_sweep": (tot_r + tot_w) / sweeps, "read_bytes_pe
                  "sweeps_measured": sweeps},
        "per_kernel": per,
        "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as read; KiB -> bytes; library kernels only"}
+# digest of the kernel sources the counters were taken with (bench.py withholds the value once they have changed)
+import hashlib, os  # noqa: E401,E402
+_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pacednegatives_amd", "csrc")
+_h = hashlib.sha256()
+for _f in sorted(os.listdir(_d)):
+    with open(os.path.join(_d, _f), "rb") as _fh:
+        _h.update(_f.encode() + b"\0" + _fh.read())
+out["kernel_sources_sha256"] = _h.hexdigest()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for n, v in sorted(per.items(), key=lambda kv: -kv[1]["read_bytes_per_sweep"]):
     print(f"{n[:70]:70s} launches/sweep={v['launches_per_sweep']:7.1f} rd={v['read_bytes_per_sweep']/1e9:8.3f} GB wr={v['write_bytes_per_sweep']/1e9:8.3f} GB")

@@ -39,6 +39,14 @@ summary = {"per_kernel": out,
            "gemm_phased_kernel": pooled(["gemm_phased_kernel"]),                                              # the dominant kernel
            "all_gemm_kernels": pooled(["gemm_phased_kernel", "gemm_bf16_kernel", "gemm_ring_kernel"]),        # every paced_gemm_bf16 launch
            "note": "FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE as read; KiB -> bytes; per launch = total / dispatches"}
+# digest of the kernel sources the counters were taken with (bench.py withholds the value once they have changed)
+import hashlib, os  # noqa: E401,E402
+_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pacednegatives_amd", "csrc")
+_h = hashlib.sha256()
+for _f in sorted(os.listdir(_d)):
+    with open(os.path.join(_d, _f), "rb") as _fh:
+        _h.update(_f.encode() + b"\0" + _fh.read())
+summary["kernel_sources_sha256"] = _h.hexdigest()
 json.dump(summary, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:14]:
     print(f"{k[:64]:64s} n={v['launches']:5d} rd/launch={v['read_bytes_per_launch']/1e6:9.1f} MB wr/launch={v['write_bytes_per_launch']/1e6:9.1f} MB")
