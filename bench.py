@@ -281,6 +281,31 @@ def run_mining(args, rank, world, device):
                                     "HBM binds below that many queries per pass"}}
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    if world == 1 and not args.skip_small_q:
+        # The same sweep where the pool's bytes bind (Q below the ridge): the HBM-streaming kernel takes it up to 64 queries.
+        regime = []
+        for entry, Qs in (("paced_pool_topk", 64), ("paced_pool_topk", 256), ("paced_pool_topk_static", 64)):
+            qs = queries[:Qs].contiguous()
+            if entry == "paced_pool_topk":
+                ws_s = torch.empty(K._lib.load().paced_pool_topk_workspace_bytes(Qs, k), dtype=torch.uint8, device=device)
+                run = lambda: K.pool_topk(qs, pool, k, workspace=ws_s)  # noqa: E731
+            else:
+                os_, oi_ = torch.empty(Qs, k, device=device), torch.empty(Qs, k, dtype=torch.int64, device=device)
+                run = lambda: K.pool_topk_static(qs, pool, k, os_, oi_)  # noqa: E731
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            el_s = (time.perf_counter() - t0) / 3
+            b_alg = Np * D * 2 + Qs * D * 2 + Qs * k * 12
+            regime.append({"entry": entry, "queries": Qs, "ms_per_sweep": el_s * 1e3, "scores_per_s": Qs * Np / el_s,
+                           "roofline": {"bound": "hbm", "achieved": b_alg / el_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                        "frac": b_alg / el_s / HBM_PEAK, "algorithmic_bytes": b_alg,
+                                        "mfma_frac": 2.0 * Qs * Np * D / el_s / BF16_DENSE_PEAK}})
+            del run
+        out["hbm_regime"] = regime
     return out
 
 
@@ -303,6 +328,7 @@ def main():
     ap.add_argument("--mine_queries", type=int, default=4096)
     ap.add_argument("--mine_k", type=int, default=1000)
     ap.add_argument("--mine_iters", type=int, default=2)
+    ap.add_argument("--skip-small-q", dest="skip_small_q", action="store_true", help="skip the pool sweeps at 64 / 256 queries")
     ap.add_argument("--launch-timeout", dest="launch_timeout", type=float, default=1500.0,
                     help="seconds after which a self-launched multi-rank run is stopped")
     args = ap.parse_args()

@@ -60,3 +60,7 @@ __host__ __device__ __forceinline__ unsigned int topk_key_row(unsigned long long
 int paced_gemm_launch(const GemmParams& p, bool trans_a, bool trans_b, int epilogue, int splits, hipStream_t stream);
 
 
+
+// Pool scoring for at most 128 queries with the HBM-streaming kernel (EPI_TOPK_FILTER's contract: p.A pool rows [M, K],
+// p.B queries [N, K], p.tk_*); PACED_ERR_ARG when the shape is outside what it covers (the caller then takes the tiled kernel).
+int paced_pool_stream_launch(const GemmParams& p, hipStream_t stream);

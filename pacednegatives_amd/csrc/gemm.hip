@@ -924,6 +924,214 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pool scoring for FEW queries (Q <= 128; taken by default up to 64): the regime where the pool's bytes bind (Q FLOP per pool byte against a
+// ridge of ~312), served by a kernel built around the HBM stream instead of the matrix cores.
+//   * The queries never touch LDS: wave w keeps the MFMA B fragments of queries 16w .. 16w+15 for the whole
+//     contraction (D/32 fragments of 4 registers) in registers for the whole launch.
+//   * All of a workgroup's LDS bandwidth and capacity serve the pool rows: a ring of NS tiles of 128 rows x 64
+//     columns (16 KiB each, the K-contiguous image of the small-tile kernels), filled by LDS-DMA; NS - 1 tiles stay in
+//     flight per compute unit and the stream runs on across the workgroup's row blocks, so the only drain is at the
+//     end of the launch (or at a flush, below).
+//   * Scores that pass their query's threshold (read once per launch: a threshold that is stale is still a valid lower
+//     bound) are collected in an LDS list and flushed to the candidate lists in bulk -- one returning global atomic per
+//     query and flush -- because a returning atomic per row block would have to wait for every older LDS-DMA, i.e.
+//     drain the ring once per block.
+// NW = ceil(Q / 16) waves; a row block of 128 pool rows is D/64 K steps of {counted wait | barrier | issue the tile NS-1
+// steps ahead | 16 fragment reads, 16 MFMAs}.  Up to 64 queries: 4 waves, 4 ring slots, TWO workgroups per compute unit,
+// so that one workgroup's fragment reads and MFMAs run under the other's waits (one workgroup alone serialises its K step
+// and reaches 4.1 TB/s); up to 128: 8 waves, 8 slots, one workgroup.
+constexpr int PS_TILE = 16384;              // bytes per ring slot
+// (entries of the LDS survivor list, a template parameter LIST: at least 4 rows x the launch's queries, which is what is
+// appended between two checks of its fill)
+constexpr int PS_MAXF = 24;                 // D <= 768: fragments per wave
+constexpr int PS_MAXQ = 128;                // queries per launch
+
+template <int LIST>
+struct PoolStreamLds {
+    static constexpr int kList = LIST;
+    unsigned long long key[LIST];
+    unsigned short qry[LIST];
+    unsigned int blk_count[32];             // passing scores of the current row block, per group of 4 rows sixteen apart
+    unsigned int list_count;
+    unsigned int qcount[PS_MAXQ];
+    unsigned int qbase[PS_MAXQ];
+};
+
+// LDS-DMA of stream position s (row block s / KS of this workgroup, K step s % KS) into its ring slot; positions past the
+// end issue the same instructions through an empty descriptor (zeros nobody reads), so that wait counts stay uniform.
+template <int NW, int NS>
+__device__ __forceinline__ void pool_stream_issue(const GemmParams& p, char* smem, int s, int total_steps, int KS, int b, int G, int w,
+                                                  const uint32_t (&offA)[16 / NW]) {
+    __amdgpu_buffer_rsrc_t r;
+    uint32_t soff = 0;
+    if (s < total_steps) {
+        const int blk = b + (s / KS) * G, m0 = blk * 128;
+        const int rows = min(128, p.M - m0);
+        r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, (uint32_t)(((size_t)(rows - 1) * p.lda + p.K) * 2), 0x00020000);
+        soff = (uint32_t)(s % KS) * (BK * 2);
+    } else {
+        r = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+    }
+    char* dst = smem + (s % NS) * PS_TILE;
+#pragma unroll
+    for (int i = 0; i < 16 / NW; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(dst + (i * NW + w) * 1024), 16, offA[i], soff, 0, 0);
+}
+
+// Survivors of the LDS list to the candidate lists: histogram per query, one returning atomic per query with survivors
+// (inline assembly with its own wait: this is the one place that drains the ring), scatter.  Called by every thread.
+template <int NW, class Lds>
+__device__ __forceinline__ void pool_stream_flush(const GemmParams& p, Lds& L, int tid) {
+    __syncthreads();
+    const unsigned int cnt = min(L.list_count, (unsigned int)Lds::kList);
+    for (unsigned int e = tid; e < cnt; e += NW * 64) atomicAdd(&L.qcount[L.qry[e]], 1u);
+    __syncthreads();
+    for (int q = tid; q < p.N; q += NW * 64) {
+        const unsigned int c = L.qcount[q];
+        if (c) {
+            unsigned int base;
+            unsigned int* slot = p.tk_cnt + q;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(base) : "v"(slot), "v"(c) : "memory");
+            L.qbase[q] = base;
+            L.qcount[q] = 0;
+        }
+    }
+    __syncthreads();
+    for (unsigned int e = tid; e < cnt; e += NW * 64) {
+        const unsigned int q = L.qry[e];
+        const unsigned int at = L.qbase[q] + atomicAdd(&L.qcount[q], 1u);
+        if (at < (unsigned int)p.tk_cap) p.tk_cand[(size_t)q * p.tk_cap + at] = L.key[e];
+    }
+    __syncthreads();
+    for (int q = tid; q < p.N; q += NW * 64) L.qcount[q] = 0;
+    if (tid == 0) L.list_count = 0;
+    __syncthreads();
+}
+
+template <int NW, int NS, int LIST>
+__global__ void __launch_bounds__(NW * 64) pool_stream_kernel(GemmParams p, int nblocks) {
+    constexpr int IA = 16 / NW;              // LDS-DMA instructions per wave and tile
+    static_assert(16 % NW == 0 && NS >= 3 && (NS - 2) * IA <= 63 && NW * 16 <= PS_MAXQ && LIST >= 4 * NW * 16, "tile split over the waves; pending count must fit vmcnt");
+    using Lds = PoolStreamLds<LIST>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds& L = *reinterpret_cast<Lds*>(smem + NS * PS_TILE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, b = blockIdx.x;
+    const int KS = p.K / BK;                 // K steps per row block
+    const int nf = p.K / 32;                 // B fragments per wave
+
+    // ---- queries of this wave into registers (hidden loads: see epilogue_rows_impl for why the compiler must not see them)
+    const int n = w * 16 + (lane & 15);
+    const int nc = min(n, p.N - 1);          // lanes past Q score a copy of the last query; their scores are never kept
+    bf16x8 fb[PS_MAXF];
+#pragma unroll
+    for (int f = 0; f < PS_MAXF; ++f) {
+        const bf16* src = p.B + (size_t)nc * p.ldb + min(f, nf - 1) * 32 + (lane >> 4) * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fb[f]) : "v"(src) : "memory");
+    }
+    float thr;
+    {
+        const float* src = p.tk_thr + nc;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(thr) : "v"(src) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0) ; hidden-load wait" : "+v"(thr) :: "memory");
+#pragma unroll
+    for (int f = 0; f < PS_MAXF; ++f) asm volatile("" : "+v"(fb[f]));
+    if (n >= p.N) thr = INFINITY;
+    if (tid < 32) L.blk_count[tid] = 0;
+    if (tid == 0) L.list_count = 0;
+    for (int i = tid; i < PS_MAXQ; i += NW * 64) L.qcount[i] = 0;
+
+    uint32_t offA[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) offA[i] = stage_offset<false, 128>((i * NW + w) * 64 + lane, p.lda);
+    const int my_blocks = b < nblocks ? (nblocks - b + G - 1) / G : 0;
+    const int total_steps = my_blocks * KS;
+
+    // stream position s = (block index of this workgroup) * KS + K step
+    auto issue = [&](int s) { pool_stream_issue<NW, NS>(p, smem, s, total_steps, KS, b, G, w, offA); };
+
+    auto flush = [&]() { pool_stream_flush<NW>(p, L, tid); };
+    constexpr unsigned int PS_LIST = LIST;
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    unsigned int pending = 0;                        // entries in the LDS list (same value in every thread)
+    bool clear_counts = false;
+    for (int blk_i = 0, s = 0; blk_i < my_blocks; ++blk_i) {
+        // the K steps of a row block, unrolled: the B fragment of a step is then a fixed register
+#pragma unroll
+        for (int ks = 0; ks < PS_MAXF / 2; ++ks) {
+            if (ks >= KS) break;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IA) : "memory");
+            PACED_PINNED_BARRIER();
+            if (clear_counts) { if (tid < 32) L.blk_count[tid] = 0; clear_counts = false; }
+            issue(s + NS - 1);
+            const char* tile = smem + (s % NS) * PS_TILE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fa[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fa[i] = read_frag<false, 128>(tile, i * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[2 * ks + kk], acc[i], 0, 0, 0);
+            }
+            ++s;
+        }
+        // ---- row block done: keep what passes.  lane -> query, registers -> 4 consecutive pool rows per 16-row sub-block
+        const int m0 = (b + blk_i * G) * 128;
+        unsigned int pass = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + (lane >> 4) * 4 + r;
+                pass |= (acc[i][r] >= thr && m < p.M ? 1u : 0u) << (i * 4 + r);
+            }
+        // Counts per register position (bit = 4 * sub-block + r: 4 lane groups x Q queries <= 1024 scores each), so that
+        // what is appended between two checks of the list's fill never exceeds the list.
+        if (pass) {
+#pragma unroll
+            for (int bit = 0; bit < 32; ++bit)
+                if ((pass >> bit) & 1u) atomicAdd(&L.blk_count[bit], 1u);
+        }
+        __syncthreads();
+        unsigned int total = 0;
+        u32x4 c32[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            c32[i] = *reinterpret_cast<const u32x4*>(&L.blk_count[4 * i]);
+            total += c32[i][0] + c32[i][1] + c32[i][2] + c32[i][3];
+        }
+        if (total) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned int c = c32[i][r];
+                    if (c == 0) continue;
+                    if (pending + c > (unsigned int)PS_LIST) { flush(); pending = 0; }
+                    if ((pass >> (i * 4 + r)) & 1u) {
+                        const unsigned int at = atomicAdd(&L.list_count, 1u);
+                        const int m = m0 + i * 16 + (lane >> 4) * 4 + r;
+                        if (at < (unsigned int)PS_LIST) { L.key[at] = topk_key(acc[i][r], p.tk_row_base + (unsigned int)m); L.qry[at] = (unsigned short)n; }
+                    }
+                    pending += c;
+                }
+            clear_counts = true;                     // after the next barrier: every thread has read the counts by then
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (pending) flush();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 namespace {
 
 // Process-wide defaults (benchmarks and tests set them through paced_gemm_set_*) and the options of the call under way on
@@ -1127,6 +1335,33 @@ extern "C" int paced_gemm_get_grid(void) { return g_grid_limit; }
 extern "C" int paced_gemm_set_ring(int on) {
     g_ring = on ? 1 : 0;
     return PACED_OK;
+}
+
+// Scores pool rows [M, K] (p.A) against p.N <= 128 queries (p.B) and appends what passes the thresholds (EPI_TOPK_FILTER's
+// contract) with the streaming kernel above.  Returns PACED_ERR_ARG when the shape is outside what that kernel covers.
+template <int NW, int NS, int LIST, int PER_CU>
+static int launch_pool_stream(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem = NS * PS_TILE + (int)sizeof(PoolStreamLds<LIST>);
+    static_assert(PER_CU * smem <= 163840, "rings and survivor lists must fit the 160 KiB of a compute unit");
+    static PerDeviceOnce once;               // one per instantiation
+    bool& attr_set = once.flag();
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_stream_kernel<NW, NS, LIST>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) { paced_set_error("hipFuncSetAttribute(%d bytes LDS) failed: %s", smem, hipGetErrorString(e)); return PACED_ERR_HIP; }
+        attr_set = true;
+    }
+    const int nblocks = (p.M + 127) / 128;
+    const int grid = nblocks < PER_CU * cu_count() ? nblocks : PER_CU * cu_count();
+    hipLaunchKernelGGL((pool_stream_kernel<NW, NS, LIST>), dim3(grid), dim3(NW * 64), smem, stream, p, nblocks);
+    PACED_CHECK_LAUNCH();
+    return PACED_OK;
+}
+
+int paced_pool_stream_launch(const GemmParams& p, hipStream_t stream) {
+    if (p.N > PS_MAXQ || p.K > PS_MAXF * 32 || p.K % BK != 0 || p.M <= 0) return PACED_ERR_ARG;
+    // (three workgroups of three slots per unit: 3.95 ms per 10 M-row sweep against 3.86 for two of four)
+    if (p.N <= 64) return launch_pool_stream<4, 4, 1024, 2>(p, stream);
+    return launch_pool_stream<8, 8, 1024, 1>(p, stream);
 }
 
 int paced_gemm_launch(const GemmParams& p, bool trans_a, bool trans_b, int epilogue, int splits, hipStream_t s) {

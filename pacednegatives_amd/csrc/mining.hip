@@ -7,10 +7,14 @@
 // (score, ~row), to that query's candidate list.  A selection kernel (8-pass byte radix select over
 // the keys, then an in-place compaction) trims a list back to its k best whenever it has grown to
 // 2k and raises the threshold.  The first chunk is written densely (no atomics) to seed the
-// thresholds; chunk sizes double up to CH_MAX so that the expected number of survivors per chunk
-// stays about k.  Candidate capacity 2k + CH_MAX per query makes overflow impossible.  A final
+// thresholds; chunk sizes double up to a maximum so that the expected number of survivors per chunk
+// stays about k.  Candidate capacity 2k + (largest chunk) per query makes overflow impossible.  The largest
+// chunk is 131072 rows for many queries and grows to 2^20 rows for few (ch_max_for): with Q below the ridge
+// of ~312 queries per pass the sweep is bound by the pool's bytes, a chunk's product takes only ~30 us per
+// 131072 rows, and the per-chunk selection launch and the launch gaps would otherwise be half the sweep.  A final
 // bitonic sort in LDS orders each query's k keys: (score descending, pool row ascending).
 #include "gemm.h"
+#include <cstdlib>
 #include <mutex>
 
 namespace {
@@ -19,7 +23,10 @@ constexpr int CH_FIRST = 4096;
 constexpr int CH_MAX = 131072;
 constexpr int K_MAX = 4096;
 
-__host__ __device__ inline int cap_for(int k) { return 2 * k + CH_MAX; }
+// largest chunk (pool rows per scoring launch) for Q queries: the candidate lists (Q x (2k + chunk) keys of 8 bytes)
+// stay within ~0.5 GB
+inline int ch_max_for(int Q) { return Q <= 64 ? 1 << 20 : Q <= 128 ? 1 << 19 : Q <= 256 ? 1 << 18 : CH_MAX; }
+inline int cap_for(int k, int Q) { return 2 * k + ch_max_for(Q); }
 
 __global__ void topk_init_kernel(unsigned int* cnt, float* thr, int Q, unsigned int cnt0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,7 +185,7 @@ int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 extern "C" size_t paced_pool_topk_workspace_bytes(int Q, int k) {
     if (Q <= 0 || k <= 0) return 0;
     const size_t head = ((size_t)Q * 8 + 255) / 256 * 256;
-    return head + (size_t)Q * cap_for(k) * 8;
+    return head + (size_t)Q * cap_for(k, Q) * 8;
 }
 
 namespace {
@@ -194,6 +201,10 @@ int pool_topk_sweep(const void* queries, const void* pool, int Q, long long Np, 
     p.tk_cand = cand; p.tk_cnt = cnt; p.tk_thr = thr; p.tk_cap = cap;
     p.batch = 1;
 
+    static int stream_env = -1;          // PACED_POOL_STREAM=0: always the tiled kernel (A/B runs)
+    if (stream_env < 0) { const char* e = getenv("PACED_POOL_STREAM"); stream_env = e ? atoi(e) : 1; }
+    const int stream_maxq = stream_env > 1 ? stream_env : 64;      // PACED_POOL_STREAM=128: also the 8-wave form (65..128 queries)
+    const bool stream_ok = stream_env && Q <= stream_maxq && D <= 768 && ((size_t)D * 2 * 128) < 0x7FFFFFFFull;
     // chunk 0: dense write, then select
     long long done = 0;
     int chunk = (int)(Np < CH_FIRST ? Np : CH_FIRST);
@@ -205,10 +216,15 @@ int pool_topk_sweep(const void* queries, const void* pool, int Q, long long Np, 
     PACED_CHECK_LAUNCH();
     done = chunk;
     while (done < Np) {
-        long long next = done < ch_max ? done : ch_max;       // double until ch_max
+        // double until ch_max; with the streaming kernel (a launch costs ~30 us whatever its size, a selection ~30 us
+        // more) quadruple: 3k survivors per query and chunk instead of k, half as many launches before the full-size chunks
+        long long next = stream_ok ? 3 * done : done;
+        if (next > ch_max) next = ch_max;
         if (next > Np - done) next = Np - done;
         p.A = (const bf16*)pool + (size_t)done * D; p.M = (int)next; p.tk_row_base = (unsigned int)done;
-        if (int e = paced_gemm_launch(p, false, false, EPI_TOPK_FILTER, 1, s)) return e;
+        // few queries: the sweep is bound by the pool's bytes and takes the streaming kernel; else the tiled MFMA kernel
+        if (!stream_ok || paced_pool_stream_launch(p, s) != PACED_OK)
+            if (int e = paced_gemm_launch(p, false, false, EPI_TOPK_FILTER, 1, s)) return e;
         hipLaunchKernelGGL(topk_select_kernel, dim3(Q), dim3(256), 0, s, cand, cnt, thr, cap, k, (unsigned int)(2 * k));
         PACED_CHECK_LAUNCH();
         done += next;
@@ -237,7 +253,7 @@ extern "C" int paced_pool_topk(const void* queries, const void* pool, int Q, lon
     float* thr = reinterpret_cast<float*>(cnt + Q);
     const size_t head = ((size_t)Q * 8 + 255) / 256 * 256;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + head);
-    return pool_topk_sweep(queries, pool, Q, Np, D, k, index_base, out_scores, out_idx, cnt, thr, cand, cap_for(k), CH_MAX,
+    return pool_topk_sweep(queries, pool, Q, Np, D, k, index_base, out_scores, out_idx, cnt, thr, cand, cap_for(k, Q), ch_max_for(Q),
                            (hipStream_t)stream);
 }
 

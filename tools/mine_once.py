@@ -12,5 +12,6 @@ ap.add_argument("--mine_k", type=int, default=1000)
 ap.add_argument("--mine_iters", type=int, default=2)
 args = ap.parse_args()
 args.no_cpu_baseline = True
+args.skip_small_q = True
 torch.cuda.set_device(0)
 print(bench.run_mining(args, 0, 1, torch.device("cuda:0")))
