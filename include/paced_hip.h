@@ -244,9 +244,11 @@ int paced_eta_bound_meta(const float* pce, const float* nce, const float* eta, f
  * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= step_size * m/(sqrt(v)+eps); p -= decay*p;
  * g is multiplied by grad_scale first (1/world_size after a summing all-reduce).  step_size and
  * decay are host scalars (lr * sqrt(1-b2^t)/(1-b1^t) and lr*wd).  p_bf16 (may be NULL) receives the
- * rounded parameters the kernels read. */
-int paced_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n,
-                float beta1, float beta2, float eps, float step_size, float decay, float grad_scale, void* stream);
+ * rounded parameters the kernels read.  clear_grad != 0: g is set to zero once read (optimizer.zero_grad(), lceT5.py:153,
+ * folded into the update: the next backward pass accumulates into g). */
+int paced_adamw(float* p, float* g, float* m, float* v, void* p_bf16, size_t n,
+                float beta1, float beta2, float eps, float step_size, float decay, float grad_scale, int clear_grad,
+                void* stream);
 
 /* ---- paced negative-pool selection ---------------------------------------------------------------
  * Replaces the retriever call of pacednegatives/utilities/compute_all_bm25.py:26-27,36 by a dense

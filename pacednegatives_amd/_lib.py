@@ -61,7 +61,7 @@ SIGNATURES = {
     "paced_lce_weights": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "paced_eta_weights": (_i, [_vp, _vp, _f, _i, _vp, _vp, _i, _vp]),
     "paced_eta_bound_meta": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
-    "paced_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _vp]),
+    "paced_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _i, _vp]),
     "paced_pool_topk_workspace_bytes": (_sz, [_i, _i]),
     "paced_pool_topk": (_i, [_vp, _vp, _i, _ll, _i, _i, _ll, _vp, _vp, _vp, _sz, _vp]),
     "paced_pool_topk_static_bytes": (_sz, []),

@@ -524,7 +524,10 @@ __global__ void relbias_table_bwd_kernel(const float* __restrict__ dtbl, const i
 // Hugging Face AdamW (the optimiser the reference constructs): m = b1 m + (1-b1) g;
 // v = b2 v + (1-b2) g^2; p -= step_size * m / (sqrt(v) + eps); then p -= lr*wd*p.  step_size
 // (= lr * sqrt(1-b2^t)/(1-b1^t)) is computed on the host.  Also refreshes the bf16 shadow copy.
-__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// CLEAR: the gradient is set to zero once it has been read (the next backward pass accumulates into it), which saves the
+// separate fill pass over the buffer.
+template <bool CLEAR>
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16* __restrict__ pb, size_t n,
                                                    float b1, float b2, float eps, float step_size, float decay, float gscale) {
     const size_t n4 = n >> 2;
@@ -547,6 +550,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
         *reinterpret_cast<f32x4*>(m + c * 4) = mv;
         *reinterpret_cast<f32x4*>(v + c * 4) = vv;
         if (pb) *reinterpret_cast<bf16x4*>(pb + c * 4) = o;
+        if (CLEAR) *reinterpret_cast<f32x4*>(g + c * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
@@ -557,6 +561,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
         pj -= decay * pj;
         p[i] = pj; m[i] = mj; v[i] = vj;
         if (pb) pb[i] = f2bf(pj);
+        if (CLEAR) g[i] = 0.f;
     }
 }
 
@@ -693,12 +698,17 @@ extern "C" int paced_relbias_table_bwd(const float* dtbl, int replicas, const in
     return PACED_OK;
 }
 
-extern "C" int paced_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n,
-                           float beta1, float beta2, float eps, float step_size, float decay, float grad_scale, void* stream) {
+extern "C" int paced_adamw(float* p, float* g, float* m, float* v, void* p_bf16, size_t n,
+                           float beta1, float beta2, float eps, float step_size, float decay, float grad_scale, int clear_grad,
+                           void* stream) {
     PACED_CHECK_ARG(p && g && m && v && n > 0, "paced_adamw: bad arguments");
     PACED_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)p_bf16 & 7) == 0, "paced_adamw: misaligned buffers");
-    hipLaunchKernelGGL(adamw_kernel, dim3(flat_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
-                       p, g, m, v, (bf16*)p_bf16, n, beta1, beta2, eps, step_size, decay, grad_scale);
+    if (clear_grad)
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3(flat_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
+                           p, g, m, v, (bf16*)p_bf16, n, beta1, beta2, eps, step_size, decay, grad_scale);
+    else
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3(flat_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
+                           p, g, m, v, (bf16*)p_bf16, n, beta1, beta2, eps, step_size, decay, grad_scale);
     PACED_CHECK_LAUNCH();
     return PACED_OK;
 }

@@ -412,7 +412,7 @@ def eta_bound_meta(pce, nce, eta, v, out, *, mask=0.0):
     _lib.check(lib.paced_eta_bound_meta(_p(pce), _p(nce), _p(eta), float(mask), _p(v), _p(out), R, _stream()), "paced_eta_bound_meta")
 
 
-def adamw(p, g, m, v, p_bf16, *, beta1=0.9, beta2=0.999, eps=1e-6, step_size, decay=0.0, grad_scale=1.0):
+def adamw(p, g, m, v, p_bf16, *, beta1=0.9, beta2=0.999, eps=1e-6, step_size, decay=0.0, grad_scale=1.0, clear_grad=False):
     lib = _lib.load()
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, n)
@@ -420,7 +420,7 @@ def adamw(p, g, m, v, p_bf16, *, beta1=0.9, beta2=0.999, eps=1e-6, step_size, de
     _chk(p_bf16, BF16, "p_bf16")
     assert p_bf16 is None or (p_bf16.is_contiguous() and p_bf16.numel() == p.numel())
     _lib.check(lib.paced_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), beta1, beta2, eps, step_size, decay, grad_scale,
-                               _stream()), "paced_adamw")
+                               int(bool(clear_grad)), _stream()), "paced_adamw")
 
 
 def pool_topk(queries, pool, k, *, index_base=0, workspace=None):

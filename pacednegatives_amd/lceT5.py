@@ -181,13 +181,13 @@ class FusedAdamW:
             return
         self.g32.zero_()
 
-    def _update(self, lo, hi, grad_scale):
+    def _update(self, lo, hi, grad_scale, clear_grad=False):
         b1, b2 = self.betas
         lr = self.param_groups[0]["lr"]
         step_size = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         p16 = self.p16[lo:hi] if self.p16 is not None else None
         K.adamw(self.p32[lo:hi], self.g32[lo:hi], self.m[lo:hi], self.v[lo:hi], p16, beta1=b1, beta2=b2, eps=self.eps,
-                step_size=step_size, decay=lr * self.weight_decay, grad_scale=grad_scale)
+                step_size=step_size, decay=lr * self.weight_decay, grad_scale=grad_scale, clear_grad=clear_grad)
 
     def step_range(self, lo: int, hi: int, grad_scale: float = 1.0):
         """Update elements [lo, hi) now, on the current stream, and clear their gradients: for callers that know the
@@ -196,8 +196,7 @@ class FusedAdamW:
         if self._early is None:
             self.t += 1
             self._early = []
-        self._update(lo, hi, grad_scale)
-        self.g32[lo:hi].zero_()
+        self._update(lo, hi, grad_scale, clear_grad=True)         # the update clears the gradients it has consumed
         self._early.append((lo, hi))
 
     def pending_ranges(self):
@@ -217,11 +216,11 @@ class FusedAdamW:
     def step(self, grad_scale: float = 1.0):
         if self._early is None:
             self.t += 1
-            self._update(0, self.p32.numel(), grad_scale)
+            self._update(0, self.p32.numel(), grad_scale, clear_grad=True)
+            self._cleared = True
             return
         for lo, hi in self.pending_ranges():
-            self._update(lo, hi, grad_scale)
-            self.g32[lo:hi].zero_()
+            self._update(lo, hi, grad_scale, clear_grad=True)
         self._early = None
         self._cleared = True
 

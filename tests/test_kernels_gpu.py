@@ -904,7 +904,9 @@ def test_adamw_matches_hf_rule():
     lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-6
     for t in range(1, 4):
         step = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-        K.adamw(p, g.to(DEV), m, v, pb, step_size=step)
+        gd = g.to(DEV)
+        K.adamw(p, gd, m, v, pb, step_size=step, clear_grad=(t == 2))
+        assert torch.equal(gd, torch.zeros_like(gd) if t == 2 else g.to(DEV))      # cleared only when asked, after it was read
         mr = b1 * mr + (1 - b1) * g.double()
         vr = b2 * vr + (1 - b2) * g.double() ** 2
         pr = pr - step * mr / (vr.sqrt() + eps)
