@@ -282,9 +282,9 @@ def run_mining(args, rank, world, device):
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if world == 1 and not args.skip_small_q:
-        # The same sweep where the pool's bytes bind (Q below the ridge): the HBM-streaming kernel takes it up to 64 queries.
+        # The same sweep where the pool's bytes bind (Q below the ridge): the HBM-streaming kernel takes it up to 128 queries.
         regime = []
-        for entry, Qs in (("paced_pool_topk", 64), ("paced_pool_topk", 256), ("paced_pool_topk_static", 64)):
+        for entry, Qs in (("paced_pool_topk", 64), ("paced_pool_topk", 128), ("paced_pool_topk", 256), ("paced_pool_topk_static", 64)):
             qs = queries[:Qs].contiguous()
             if entry == "paced_pool_topk":
                 ws_s = torch.empty(K._lib.load().paced_pool_topk_workspace_bytes(Qs, k), dtype=torch.uint8, device=device)

@@ -942,6 +942,9 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
 // so that one workgroup's fragment reads and MFMAs run under the other's waits (one workgroup alone serialises its K step
 // and reaches 4.1 TB/s); up to 128: 8 waves, 8 slots, one workgroup.
 constexpr int PS_TILE = 16384;              // bytes per ring slot
+#ifndef PS_AUX
+#define PS_AUX 2                            // cache-policy bits of the pool stream's LDS-DMA: 2 = nt, the rows are read once (0: 2 % slower)
+#endif
 // (entries of the LDS survivor list, a template parameter LIST: at least 4 rows x the launch's queries, which is what is
 // appended between two checks of its fill)
 constexpr int PS_MAXF = 24;                 // D <= 768: fragments per wave
@@ -976,7 +979,7 @@ __device__ __forceinline__ void pool_stream_issue(const GemmParams& p, char* sme
     char* dst = smem + (s % NS) * PS_TILE;
 #pragma unroll
     for (int i = 0; i < 16 / NW; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(dst + (i * NW + w) * 1024), 16, offA[i], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(dst + (i * NW + w) * 1024), 16, offA[i], soff, 0, PS_AUX);
 }
 
 // Survivors of the LDS list to the candidate lists: histogram per query, one returning atomic per query with survivors
@@ -1064,25 +1067,28 @@ __global__ void __launch_bounds__(NW * 64) pool_stream_kernel(GemmParams p, int 
     unsigned int pending = 0;                        // entries in the LDS list (same value in every thread)
     bool clear_counts = false;
     for (int blk_i = 0, s = 0; blk_i < my_blocks; ++blk_i) {
-        // the K steps of a row block, unrolled: the B fragment of a step is then a fixed register
-#pragma unroll
-        for (int ks = 0; ks < PS_MAXF / 2; ++ks) {
-            if (ks >= KS) break;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IA) : "memory");
-            PACED_PINNED_BARRIER();
-            if (clear_counts) { if (tid < 32) L.blk_count[tid] = 0; clear_counts = false; }
-            issue(s + NS - 1);
-            const char* tile = smem + (s % NS) * PS_TILE;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fa[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) fa[i] = read_frag<false, 128>(tile, i * 16, kk, lane);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[2 * ks + kk], acc[i], 0, 0, 0);
-            }
-            ++s;
+        // The K steps of a row block, unrolled by hand (a macro, not a loop: with the barrier inside, the compiler keeps a
+        // loop rolled, indexes the B fragments dynamically and parks them in scratch memory): the B fragment of a step
+        // is then a fixed register.
+#define PS_KSTEP(ks)                                                                                                   \
+        if ((ks) < KS) {                                                                                               \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IA) : "memory");                                        \
+            PACED_PINNED_BARRIER();                                                                                    \
+            if (clear_counts) { if (tid < 32) L.blk_count[tid] = 0; clear_counts = false; }                            \
+            issue(s + NS - 1);                                                                                         \
+            const char* tile = smem + (s % NS) * PS_TILE;                                                              \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                         \
+                bf16x8 fa[8];                                                                                          \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = read_frag<false, 128>(tile, i * 16, kk, lane);   \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[2 * (ks) + kk], acc[i], 0, 0, 0);       \
+            }                                                                                                          \
+            ++s;                                                                                                       \
         }
+        PS_KSTEP(0) PS_KSTEP(1) PS_KSTEP(2) PS_KSTEP(3) PS_KSTEP(4) PS_KSTEP(5)
+        PS_KSTEP(6) PS_KSTEP(7) PS_KSTEP(8) PS_KSTEP(9) PS_KSTEP(10) PS_KSTEP(11)
+#undef PS_KSTEP
+        static_assert(PS_MAXF == 24, "twelve K steps are written out above");
         // ---- row block done: keep what passes.  lane -> query, registers -> 4 consecutive pool rows per 16-row sub-block
         const int m0 = (b + blk_i * G) * 128;
         unsigned int pass = 0;

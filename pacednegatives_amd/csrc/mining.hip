@@ -203,7 +203,7 @@ int pool_topk_sweep(const void* queries, const void* pool, int Q, long long Np, 
 
     static int stream_env = -1;          // PACED_POOL_STREAM=0: always the tiled kernel (A/B runs)
     if (stream_env < 0) { const char* e = getenv("PACED_POOL_STREAM"); stream_env = e ? atoi(e) : 1; }
-    const int stream_maxq = stream_env > 1 ? stream_env : 64;      // PACED_POOL_STREAM=128: also the 8-wave form (65..128 queries)
+    const int stream_maxq = stream_env > 1 ? stream_env : 128;     // PACED_POOL_STREAM=64: the 8-wave form (65..128 queries) off
     const bool stream_ok = stream_env && Q <= stream_maxq && D <= 768 && ((size_t)D * 2 * 128) < 0x7FFFFFFFull;
     // chunk 0: dense write, then select
     long long done = 0;

@@ -984,11 +984,11 @@ def test_pool_topk_when_every_row_beats_the_threshold():
     assert np.array_equal(s.cpu().numpy(), ws)
 
 
-@pytest.mark.parametrize("Q,D", [(64, 768), (33, 128), (1, 64), (100, 256)])
+@pytest.mark.parametrize("Q,D", [(64, 768), (33, 128), (1, 64), (100, 256), (128, 768)])
 @pytest.mark.parametrize("order", ["ascending", "random"])
-def test_pool_topk_few_queries_streaming_kernel(Q, D, order, monkeypatch):
-    """Up to 64 queries the sweep takes the HBM-streaming kernel (queries in registers, pool rows through an LDS ring, survivors
-    collected in an LDS list and flushed in bulk); Q = 100 takes it when asked to.  Pools long enough for several growing
+def test_pool_topk_few_queries_streaming_kernel(Q, D, order):
+    """Up to 128 queries the sweep takes the HBM-streaming kernel (queries in registers, pool rows through an LDS ring, survivors
+    collected in an LDS list and flushed in bulk; 4 waves up to 64 queries, 8 beyond).  Pools long enough for several growing
     chunks and many row blocks per workgroup, a ragged last block, and -- "ascending" -- scores that grow with the row index,
     so that every row of every chunk passes and the list overflows into flush after flush.  Bit-exact against the oracle
     and against the tiled kernel."""
@@ -1000,8 +1000,6 @@ def test_pool_topk_few_queries_streaming_kernel(Q, D, order, monkeypatch):
     if order == "ascending":
         q[:, 0] = 1.0
         p[:, 0] = np.arange(Np) // 512                      # bf16-exact (< 256); ties inside runs of 512 rows
-    if Q > 64:
-        monkeypatch.setenv("PACED_POOL_STREAM", "128")      # read once per process: only effective in a fresh one
     qd, pd = bf(torch.from_numpy(q)), bf(torch.from_numpy(p))
     s, i = K.pool_topk(qd, pd, k, index_base=5)
     ws, wi = mining_ref.pool_topk(q, p, k)
