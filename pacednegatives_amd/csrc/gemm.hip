@@ -603,6 +603,18 @@ __device__ __forceinline__ int ring_wrap(int x) { return x >= 10 ? x - 10 : x; }
 // FULL (the tile lies inside the matrix; every store is issued): when piece n is consumed the operations younger
 // than its load are loads n+1 .. min(n+7, 15) and the stores issued since, n of them for n < 8 and 7 after that.
 // Edge tiles clamp the load addresses into the matrix, predicate the stores and wait for each batch of eight whole.
+// bf16 output rows of the phased kernel are stored non-temporally: an output (214-856 MB at the benchmark shape) is read
+// again only by a later kernel and far exceeds the caches; stored the ordinary way it evicts the weight panels and
+// activations that this launch and the launches of the other streams re-read (step 117.7 -> 115.5 ms, alternating in one job;
+// -DGEMM_NT_STORE=0 restores ordinary stores).
+#ifndef GEMM_NT_STORE
+#define GEMM_NT_STORE 1
+#endif
+__device__ __forceinline__ void st_out(bf16x8* p, bf16x8 v) {
+    if (GEMM_NT_STORE) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 template <class T>
 __device__ __forceinline__ void wait_hidden_load(int n, T& x) {
 #define PACED_WAIT_CASE(N, CNT) if (n == N) asm volatile("s_waitcnt vmcnt(" #CNT ") ; hidden-load wait" : "+v"(x) :: "memory");
@@ -721,8 +733,8 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
             else const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux))[(size_t)m * p.ldaux + (ncol >> 3)] = (unsigned char)byte;
         }
         if (EPI == EPI_BF16 && p.c_heads) {        // a wave's 64 columns are one head: rows of 128 bytes, 128 bytes apart
-            if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)(ncol >> 6) * p.c_heads + (size_t)m * 64 + (ncol & 63)) = t;
-        } else if (ok) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol) = t;
+            if (ok) st_out(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)(ncol >> 6) * p.c_heads + (size_t)m * 64 + (ncol & 63)), t);
+        } else if (ok) st_out(reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(Cb) + (size_t)m * p.ldc + ncol), t);
         if (LOADS && n < 8) {
             if (FULL) load_piece(n + 8);
             else if (n == 7) {
