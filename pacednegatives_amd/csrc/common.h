@@ -49,6 +49,19 @@ struct PerDeviceOnce {
     }
 };
 
+// compute units of the current device (256 when it cannot be asked)
+inline int paced_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

@@ -1168,17 +1168,7 @@ int eff_grid_limit() {
     return g_grid_limit;
 }
 
-int cu_count() {
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (!cached[dev]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached[dev] = n;
-    }
-    return cached[dev];
-}
+int cu_count() { return paced_cu_count(); }
 
 int g_ring = -1;         // -1 = not set yet (PACED_GEMM_RING read on first use), 0 off, 1 on (paced_gemm_set_ring)
 bool ring_enabled() {

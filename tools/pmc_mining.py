@@ -24,7 +24,7 @@ def load(d, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 sweeps = int(sys.argv[4])
-mine = [n for n in set(fetch) | set(write) if n.startswith(("void gemm_", "gemm_", "topk_", "void topk_"))]
+mine = [n for n in set(fetch) | set(write) if n.startswith(("void gemm_", "gemm_", "topk_", "void topk_", "void pool_stream_", "pool_stream_"))]
 per = {}
 tot_r = tot_w = 0.0
 for n in sorted(mine):
