@@ -1,5 +1,5 @@
 #!/bin/bash
-# Full measurement on one GPU box (round 2): GPU tests, smoke, HBM-traffic counters for the training step and for the
+# Full measurement on one GPU box (the profiles/r2_* set): GPU tests, smoke, HBM-traffic counters for the training step and for the
 # pool sweep (two separate --pmc passes each), kernel traces (default schedule, one-stream schedule, pool sweep), and
 # the default bench line.  Every GPU step runs under its own time limit; the script stops at the first failure.
 set -o pipefail

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Full measurement on one GPU box (round 3): GPU tests, smoke, HBM-traffic counters for the training step, for the pool
+# Full measurement on one GPU box (the profiles/r3_* set): GPU tests, smoke, HBM-traffic counters for the training step, for the pool
 # sweep at 4096 queries and at 64 queries (two separate --pmc passes each), kernel traces (default schedule, one-stream
 # schedule, pool sweep at 4096 and at 64 / 128 / 256 queries), and the default bench line.  Every GPU step runs under
 # its own time limit; the script stops at the first failure.   usage: tools/measure_r3.sh [notests]
