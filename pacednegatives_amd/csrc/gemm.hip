@@ -975,16 +975,17 @@ struct PoolStreamLds {
 
 // LDS-DMA of stream position s (row block s / KS of this workgroup, K step s % KS) into its ring slot; positions past the
 // end issue the same instructions through an empty descriptor (zeros nobody reads), so that wait counts stay uniform.
+// (bi, ki) = (s / KS, s % KS), kept by the caller: stream positions are issued in order, so no division is needed here.
 template <int NW, int NS>
-__device__ __forceinline__ void pool_stream_issue(const GemmParams& p, char* smem, int s, int total_steps, int KS, int b, int G, int w,
+__device__ __forceinline__ void pool_stream_issue(const GemmParams& p, char* smem, int s, int total_steps, int bi, int ki, int b, int G, int w,
                                                   const uint32_t (&offA)[16 / NW]) {
     __amdgpu_buffer_rsrc_t r;
     uint32_t soff = 0;
     if (s < total_steps) {
-        const int blk = b + (s / KS) * G, m0 = blk * 128;
+        const int blk = b + bi * G, m0 = blk * 128;
         const int rows = min(128, p.M - m0);
         r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (size_t)m0 * p.lda), 0, (uint32_t)(((size_t)(rows - 1) * p.lda + p.K) * 2), 0x00020000);
-        soff = (uint32_t)(s % KS) * (BK * 2);
+        soff = (uint32_t)ki * (BK * 2);
     } else {
         r = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
     }
@@ -1066,7 +1067,11 @@ __global__ void __launch_bounds__(NW * 64) pool_stream_kernel(GemmParams p, int 
     const int total_steps = my_blocks * KS;
 
     // stream position s = (block index of this workgroup) * KS + K step
-    auto issue = [&](int s) { pool_stream_issue<NW, NS>(p, smem, s, total_steps, KS, b, G, w, offA); };
+    int is_b = 0, is_k = 0;                 // row block and K step of the next position to be issued (positions go out in order)
+    auto issue = [&](int s) {
+        pool_stream_issue<NW, NS>(p, smem, s, total_steps, is_b, is_k, b, G, w, offA);
+        if (++is_k == KS) { is_k = 0; ++is_b; }
+    };
 
     auto flush = [&]() { pool_stream_flush<NW>(p, L, tid); };
     constexpr unsigned int PS_LIST = LIST;
@@ -1074,8 +1079,12 @@ __global__ void __launch_bounds__(NW * 64) pool_stream_kernel(GemmParams p, int 
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // One workgroup per CU (eight waves): its waves all stand at the same barrier, nobody fills the wait, so two K steps
+    // share one (two ring slots are free at a time, NS - 2 tiles in flight).  Two workgroups per CU: one K step per barrier.
+    constexpr bool PAIR = NW == 8;
+    static_assert(!PAIR || NS >= 6, "pairs of K steps need a ring of six slots or more");
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s);
+    for (int s = 0; s < NS - 1 - (PAIR ? 1 : 0); ++s) issue(s);
     unsigned int pending = 0;                        // entries in the LDS list (same value in every thread)
     bool clear_counts = false;
     for (int blk_i = 0, s = 0; blk_i < my_blocks; ++blk_i) {
@@ -1097,8 +1106,56 @@ __global__ void __launch_bounds__(NW * 64) pool_stream_kernel(GemmParams p, int 
             }                                                                                                          \
             ++s;                                                                                                       \
         }
-        PS_KSTEP(0) PS_KSTEP(1) PS_KSTEP(2) PS_KSTEP(3) PS_KSTEP(4) PS_KSTEP(5)
-        PS_KSTEP(6) PS_KSTEP(7) PS_KSTEP(8) PS_KSTEP(9) PS_KSTEP(10) PS_KSTEP(11)
+#define PS_TILE_MFMA(ks, tile)                                                                                         \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                         \
+                bf16x8 fa[8];                                                                                          \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) fa[i] = read_frag<false, 128>(tile, i * 16, kk, lane);   \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[2 * (ks) + kk], acc[i], 0, 0, 0);       \
+            }
+        // K steps ks and ks + 1 behind one barrier (the second only if the row block has it).  The row fragments go through
+        // two register sets of four by hand, each read four MFMAs before it is used: left to itself the compiler
+        // keeps two fragments in flight, and every MFMA then waits an LDS latency for its operand.
+#define PS_RD4(set, tile, kk, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) set[i] = read_frag<false, 128>(tile, (4 * (half) + i) * 16, kk, lane); __builtin_amdgcn_sched_barrier(0);
+#define PS_MM4(set, f, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[4 * (half) + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(set[i], fb[f], acc[4 * (half) + i], 0, 0, 0); __builtin_amdgcn_sched_barrier(0);
+#define PS_KPAIR(ks)                                                                                                   \
+        if ((ks) < KS) {                                                                                               \
+            const bool two = (ks) + 1 < KS;                                                                            \
+            if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 4) * IA) : "memory");                               \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IA) : "memory");                                   \
+            PACED_PINNED_BARRIER();                                                                                    \
+            if (clear_counts) { if (tid < 32) L.blk_count[tid] = 0; clear_counts = false; }                            \
+            issue(s + NS - 2);                                                                                         \
+            if (two) issue(s + NS - 1);                                                                                \
+            const char* tile0 = smem + (s % NS) * PS_TILE;                                                             \
+            const char* tile1 = smem + ((s + 1) % NS) * PS_TILE;                                                       \
+            constexpr int f0 = 2 * (ks), f1 = 2 * ((ks) + 1 < PS_MAXF / 2 ? (ks) + 1 : (ks));                          \
+            bf16x8 s0[4], s1[4];                    /* two sets of four fragments: four to eight reads stay ahead of the MFMAs */ \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            PS_RD4(s0, tile0, 0, 0) PS_RD4(s1, tile0, 0, 1)                                                             \
+            PS_MM4(s0, f0, 0) PS_RD4(s0, tile0, 1, 0)                                                                   \
+            PS_MM4(s1, f0, 1) PS_RD4(s1, tile0, 1, 1)                                                                   \
+            if (two) {                                                                                                 \
+                PS_MM4(s0, f0 + 1, 0) PS_RD4(s0, tile1, 0, 0)                                                           \
+                PS_MM4(s1, f0 + 1, 1) PS_RD4(s1, tile1, 0, 1)                                                           \
+                PS_MM4(s0, f1, 0) PS_RD4(s0, tile1, 1, 0)                                                               \
+                PS_MM4(s1, f1, 1) PS_RD4(s1, tile1, 1, 1)                                                               \
+                PS_MM4(s0, f1 + 1, 0) PS_MM4(s1, f1 + 1, 1)                                                             \
+            } else {                                                                                                   \
+                PS_MM4(s0, f0 + 1, 0) PS_MM4(s1, f0 + 1, 1)                                                             \
+            }                                                                                                          \
+            s += two ? 2 : 1;                                                                                          \
+        }
+        if (PAIR) {
+            PS_KPAIR(0) PS_KPAIR(2) PS_KPAIR(4) PS_KPAIR(6) PS_KPAIR(8) PS_KPAIR(10)
+        } else {
+            PS_KSTEP(0) PS_KSTEP(1) PS_KSTEP(2) PS_KSTEP(3) PS_KSTEP(4) PS_KSTEP(5)
+            PS_KSTEP(6) PS_KSTEP(7) PS_KSTEP(8) PS_KSTEP(9) PS_KSTEP(10) PS_KSTEP(11)
+        }
+#undef PS_KPAIR
+#undef PS_RD4
+#undef PS_MM4
+#undef PS_TILE_MFMA
 #undef PS_KSTEP
         static_assert(PS_MAXF == 24, "twelve K steps are written out above");
         // ---- row block done: keep what passes.  lane -> query, registers -> 4 consecutive pool rows per 16-row sub-block
