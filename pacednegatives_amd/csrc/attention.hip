@@ -17,6 +17,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef ATTN_ROW_STORES
+#define ATTN_ROW_STORES 1
+#endif
 namespace {
 
 constexpr int DK = 64;
@@ -211,6 +214,29 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
     return __builtin_convertvector(s2 ? hi : lo, bf16x8);
 }
 
+// A wave's 32 x 64 output tile held as accumulators (lane -> row lane & 31, 8-byte pieces of the row in registers) leaves
+// as whole 128-byte rows: through `tw` (4 KB of LDS that only this wave touches; a wave's LDS accesses stay in order),
+// then 16 bytes per lane, eight lanes per row, non-temporal.  Nobody reads these outputs before the next product does,
+// and a non-temporal store of a PARTIAL line is what is slow.  `row0` = pointer to the tile's first row, rows >= valid
+// are not stored.
+__device__ __forceinline__ void store_tile_rows(char* tw, const f32x16& a0, const f32x16& a1, float scale, bf16* row0, int ld, int valid, int lane) {
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] = f2bf(a0[4 * rg + e] * scale); v1[e] = f2bf(a1[4 * rg + e] * scale); }
+        *reinterpret_cast<bf16x4*>(tw + row_img_off(r, rg) + 8 * hh) = v0;
+        *reinterpret_cast<bf16x4*>(tw + row_img_off(r, 4 + rg) + 8 * hh) = v1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (lane >> 3) + 8 * i, c = lane & 7;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(tw + row_img_off(rr, c));
+        if (rr < valid) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(row0 + (size_t)rr * ld + c * 8));
+    }
+}
+
 }  // namespace
 
 // State of dropout quad number `quad` of the probability tensor.  WIDE = false: the tensor has at most 2^34 elements, the
@@ -327,8 +353,16 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
     if (nfull < ntile) tile(nfull, std::true_type{});
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = (DROP ? a.drop.scale : 1.f) / l_tot;
+    if (q < S && hh == 0 && a.lse) a.lse[((size_t)n * a.H + h) * S + q] = m_run + __logf(l_tot);
+#if ATTN_ROW_STORES
+    // the wave's 32 rows leave as whole rows through its quarter of the K / V area, free after the last tile
+    __syncthreads();
+    {
+        const int q0 = blockIdx.x * 128 + w * 32;
+        store_tile_rows(smem + w * 4096, o0, o1, inv, a.out + (rowbase + q0) * a.ldo + h * a.hso, a.ldo, S - q0, lane);
+    }
+#else
     if (q < S) {
-        if (hh == 0 && a.lse) a.lse[((size_t)n * a.H + h) * S + q] = m_run + __logf(l_tot);
         bf16* orow = a.out + (rowbase + q) * a.ldo + h * a.hso;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -339,6 +373,7 @@ __global__ void __launch_bounds__(256, 3) enc_attn_fwd_kernel(AttnArgs a) {
             *reinterpret_cast<bf16x4*>(orow + 32 + 8 * rg + 4 * hh) = v1;
         }
     }
+#endif
 }
 
 // ====================================================================== backward: dK, dV, dBias
@@ -528,6 +563,13 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
         if (qt < 4) STAMP(4 + 2 * qt);
     }
     STAMP(11);
+#if ATTN_ROW_STORES
+    {   // (the loop's last barrier is behind every wave's last read of the staging areas)
+        const int k0 = bx * 128 + w * 32;
+        store_tile_rows(smem + w * 4096, dk0, dk1, 1.f, a.dk + (rowbase + k0) * a.ldd + h * a.hsd, a.ldd, S - k0, lane);
+        store_tile_rows(smem + w * 4096, dv0, dv1, 1.f, a.dv + (rowbase + k0) * a.ldd + h * a.hsd, a.ldd, S - k0, lane);
+    }
+#else
     if (key < S) {
         bf16* dkrow = a.dk + (rowbase + key) * a.ldd + h * a.hsd;
         bf16* dvrow = a.dv + (rowbase + key) * a.ldd + h * a.hsd;
@@ -545,6 +587,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
             *reinterpret_cast<bf16x4*>(dvrow + 32 + 8 * rg + 4 * hh) = v1;
         }
     }
+#endif
     STAMP(12);
     if (a.dbias) {
         const int idx = (bx * 128 + w * 32 + (lane & 31)) - ntile * 32 + S - 1 - 4 * hh;   // wrapped part of the last tile
@@ -688,6 +731,13 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
 #ifdef DBG_STAMPS_DQ
     STAMP_DUMP(a.dbias);
 #endif
+#if ATTN_ROW_STORES
+    __syncthreads();             // everyone is done with the K / V images of the last tile
+    {
+        const int q0 = blk.x * 128 + w * 32;
+        store_tile_rows(smem + w * 4096, dq0, dq1, 1.f, a.dq + (rowbase + q0) * a.ldd + h * a.hsd, a.ldd, S - q0, lane);
+    }
+#else
     if (q < S) {
         bf16* dqrow = a.dq + (rowbase + q) * a.ldd + h * a.hsd;
 #pragma unroll
@@ -699,6 +749,7 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dq_kernel(AttnArgs a) {
             *reinterpret_cast<bf16x4*>(dqrow + 32 + 8 * rg + 4 * hh) = v1;
         }
     }
+#endif
 }
 
 namespace {
@@ -1241,6 +1292,7 @@ extern "C" int paced_enc_attn_fwd(const void* q, const void* k, const void* v, i
     PACED_CHECK_ARG(q && k && v && ctx, "paced_enc_attn_fwd: null operand");
     PACED_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && hs % 8 == 0 && hs >= 64 && hso % 8 == 0 && hso >= 64,
                     "paced_enc_attn_fwd: row strides must be multiples of 8, head strides multiples of 8 that are >= 64");
+    PACED_CHECK_ARG((uintptr_t)ctx % 16 == 0, "paced_enc_attn_fwd: ctx must be 16-byte aligned (whole rows are stored 16 bytes at a time)");
     AttnArgs a = {};
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld; a.hs = hs;
     a.out = (bf16*)ctx; a.ldo = ldo; a.hso = hso; a.lse = lse; a.bias = bias_tbl;
@@ -1260,9 +1312,10 @@ extern "C" int paced_enc_attn_bwd(const void* q, const void* k, const void* v, i
                                   int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream) {
     if (int e = check_common("paced_enc_attn_bwd", N, S, H, dk)) return e;
     PACED_CHECK_ARG(q && k && v && ctx && dctx && lse && dq && dk_ && dv, "paced_enc_attn_bwd: null operand");
-    PACED_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldd % 4 == 0, "paced_enc_attn_bwd: bad row strides");
-    PACED_CHECK_ARG(hs % 8 == 0 && hs >= 64 && hso % 8 == 0 && hso >= 64 && hsdo % 8 == 0 && hsdo >= 64 && hsd % 4 == 0 && hsd >= 64,
-                    "paced_enc_attn_bwd: head strides must be multiples of 8 (4 for the outputs) that are >= 64");
+    PACED_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldd % 8 == 0, "paced_enc_attn_bwd: row strides must be multiples of 8");
+    PACED_CHECK_ARG(hs % 8 == 0 && hs >= 64 && hso % 8 == 0 && hso >= 64 && hsdo % 8 == 0 && hsdo >= 64 && hsd % 8 == 0 && hsd >= 64,
+                    "paced_enc_attn_bwd: head strides must be multiples of 8 that are >= 64");
+    PACED_CHECK_ARG(((uintptr_t)dq | (uintptr_t)dk_ | (uintptr_t)dv) % 16 == 0, "paced_enc_attn_bwd: dq, dk and dv must be 16-byte aligned (whole rows are stored 16 bytes at a time)");
     AttnArgs a = {};
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.ld = ld; a.hs = hs;
     a.o = (const bf16*)ctx; a.ldo = ldo; a.hso = hso; a.dout = (const bf16*)dctx; a.lddo = lddo; a.hsdo = hsdo;
