@@ -607,6 +607,12 @@ __device__ __forceinline__ int ring_wrap(int x) { return x >= 10 ? x - 10 : x; }
 // again only by a later kernel and far exceeds the caches; stored the ordinary way it evicts the weight panels and
 // activations that this launch and the launches of the other streams re-read (step 117.7 -> 115.5 ms, alternating in one job;
 // -DGEMM_NT_STORE=0 restores ordinary stores).
+#ifndef GEMM_NT_BITS
+#define GEMM_NT_BITS 1
+#endif
+#ifndef GEMM_NT_AUX_LOAD
+#define GEMM_NT_AUX_LOAD 1
+#endif
 #ifndef GEMM_NT_STORE
 #define GEMM_NT_STORE 1
 #endif
@@ -651,7 +657,9 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
             asm volatile("global_load_ubyte %0, %1, off" : "=v"(mbits[n & 7]) : "v"(src) : "memory");
         } else {
             const bf16* src = p.aux + (size_t)mc * p.ldaux + nc;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aux[n & 7]) : "v"(src) : "memory");
+            // (the residual / mask operand is read once per launch: non-temporal, it need not stay in the L2s)
+            if (GEMM_NT_AUX_LOAD) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(aux[n & 7]) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aux[n & 7]) : "v"(src) : "memory");
         }
     };
     auto wait_batch = [&]() {
@@ -761,7 +769,10 @@ __device__ __forceinline__ void epilogue_rows_impl(const GemmParams& p, void* Cb
         finish(i, 0, t0);
         finish(i, 1, t1);
     }
-    if (TILED && EPI == EPI_RELU_DROP) *reinterpret_cast<u32x4*>(tile_bits) = tbits;
+    if (TILED && EPI == EPI_RELU_DROP) {          // read again by the backward pass only
+        if (GEMM_NT_BITS) __builtin_nontemporal_store(tbits, reinterpret_cast<u32x4*>(tile_bits));
+        else *reinterpret_cast<u32x4*>(tile_bits) = tbits;
+    }
 }
 
 template <int EPI>
@@ -840,7 +851,7 @@ __global__ void __launch_bounds__(512) gemm_phased_kernel(GemmParams p, int ntm,
         if ((EPI == EPI_RELU_DROP || EPI == EPI_MASK_BITS) && p.aux && p.ldaux < 0) {
             tile_bits = const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.aux)) +
                         ((size_t)((m0 >> 8) * ntn + (n0 >> 8)) * 512 + tid) * 16;
-            if (EPI == EPI_MASK_BITS) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tbits) : "v"(tile_bits) : "memory");
+            if (EPI == EPI_MASK_BITS) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(tbits) : "v"(tile_bits) : "memory");     // read once
         }
         for (int t = 0; t < nsteps; ++t) {
             const int sB0 = base, sA0 = ring_wrap(base + 1), sB1 = ring_wrap(base + 2), sA1 = ring_wrap(base + 3);
