@@ -30,6 +30,7 @@ import warnings
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import pacednegatives_amd  # noqa: E402,F401  (first: it sets HIP_FORCE_DEV_KERNARG before the HIP runtime initialises)
 import torch  # noqa: E402
 
 BF16_DENSE_PEAK = 2.5e15     # FLOP/s, MI355X dense bf16 MFMA
