@@ -436,8 +436,14 @@ __global__ void __launch_bounds__(256, 2) enc_attn_bwd_dkdv_kernel(AttnArgs a) {
     bf16x8 dv = bload8(rD, (sr * a.lddo + sc * 8) * 2);
     bf16x8 ov = bload8(rO, (sr * a.ldo + sc * 8) * 2);
     float lsev = bloadf(rL, sr);
+    // the sums are cleared while the loads above are in flight (8 bytes per store: LB and the table in front are even
+    // counts of floats), the bias table is staged after that
+    {
+        float2* z = reinterpret_cast<float2*>(ldb);
+        const int nz = (priv ? 8 * LB : LB) >> 1;
+        for (int i = threadIdx.x; i < nz; i += 256) z[i] = float2{0.f, 0.f};
+    }
     stage_bias(floats_rsrc(a.bias ? a.bias + (size_t)h * (2 * S - 1) : nullptr, 2 * S - 1), lbias, PAD, PAD + LB);
-    for (int i = threadIdx.x; i < (priv ? 8 * LB : LB); i += 256) ldb[i] = 0.f;
     float* ldb_own = ldb + (priv ? (2 * w + hh) * LB : 0);
     f32x16 dk0, dk1, dv0, dv1, zero16;
 #pragma unroll
