@@ -179,7 +179,9 @@ int paced_relbias_table_bwd(const float* dtbl, int replicas, const int* bucket, 
  * lse [N,H,S] fp32 (log-sum-exp of the biased scores); bias_tbl [H, 2S-1] fp32 or NULL.
  * bwd writes dq, dk, dv (same addressing, row stride ldd) and adds into dbias_tbl (may be NULL):
  * [dbias_replicas, H, 2S-1]; workgroups spread their adds over the replicas so that same-address
- * atomics do not serialise; the caller sums the replicas (paced_relbias_table_bwd does). */
+ * atomics do not serialise; the caller sums the replicas (paced_relbias_table_bwd does).
+ * Every row stride and head stride is a multiple of 8 elements, and ctx, dq, dk, dv are 16-byte aligned: the outputs are
+ * stored as whole 128-byte rows, 16 bytes per lane. */
 int paced_enc_attn_fwd(const void* q, const void* k, const void* v, int ld, long long hs, void* ctx, int ldo, long long hso, float* lse,
                        const float* bias_tbl, int N, int S, int H, int dk, float drop_p, uint32_t drop_seed, void* stream);
 int paced_enc_attn_bwd(const void* q, const void* k, const void* v, int ld, long long hs, const void* ctx, int ldo, long long hso,
